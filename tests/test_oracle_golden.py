@@ -1,0 +1,120 @@
+"""Pins the CPU oracle (oracle/shg_ref.py, oracle/lsap.c) against golden vectors produced by the
+real reference in the build container (oracle/gen_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shg_ref
+
+
+def _close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max()
+    assert np.allclose(a, b, rtol=rtol, atol=atol), f"max abs err {err}"
+
+
+def test_lsap_c_and_py_match_scipy_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "lsap_scipy.npz"))
+    n = g["cost"].shape[0]
+    assert n > 3000
+    for i in range(n):
+        nr, nc = g["shape"][i]
+        c = g["cost"][i, :nr, :nc]
+        k = min(nr, nc)
+        r, cc = shg_ref.lsap_c(c)
+        assert np.array_equal(r, g["rows"][i, :k]) and np.array_equal(cc, g["cols"][i, :k]), i
+        if i % 7 == 0:
+            r2, c2 = shg_ref.lsap_py(c)
+            assert np.array_equal(r2, r) and np.array_equal(c2, cc), i
+
+
+def test_lsap_known_answers():
+    r, c = shg_ref.lsap_c(np.zeros((8, 0)))
+    assert len(r) == 0 and len(c) == 0
+    r, c = shg_ref.lsap_c(np.full((8, 3), -0.25))
+    assert r.tolist() == [0, 1, 2] and c.tolist() == [0, 1, 2]
+    r, c = shg_ref.lsap_c(np.array([[-.5, -.5], [-.5, -.5], [-.1, -.9]]))
+    assert r.tolist() == [0, 2] and c.tolist() == [0, 1]
+
+
+def test_param_spec_is_subset_of_reference_parameters(golden_dir):
+    spec = json.load(open(os.path.join(golden_dir, "agqa_state_dict_spec.json")))
+    ref = {k: tuple(s) for k, s in spec["parameters"]}
+    mine = shg_ref.param_spec(shg_ref.Cfg())
+    for k, s in mine:
+        assert ref[k] == tuple(s), k
+    assert len(spec["state_dict"]) == 669 and len(ref) == 576
+
+
+def test_masks_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "agqa_hgqa_b2.npz"))
+    assert np.array_equal(shg_ref.frame_causal_mask(16, 8).numpy(), g["rel_mask"])
+    assert np.array_equal(shg_ref.frame_causal_mask(16, 3).numpy(), g["act_mask"])
+
+
+@pytest.mark.parametrize("tag", ["hgqa", "star"])
+def test_full_forward_loss_backward_match_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"agqa_{tag}_b2.npz"))
+    cfg = shg_ref.Cfg() if tag == "hgqa" else shg_ref.Cfg(num_answers=4, rel_classes=564, act_classes=112,
+                                                           use_hg_mask=True)
+    torch.manual_seed(0)
+    p = shg_ref.det_params(cfg, requires_grad=True)
+    batch = shg_ref.synthetic_batch(int(g["batch_size"]), cfg, seed=int(g["batch_seed"]))
+    out = shg_ref.agqa_forward(p, cfg, batch)
+    _close(out["logit"].detach(), g["logit"], 1e-4, 2e-5)
+    _close(out["hg_logit"].detach(), g["hg_logit"], 1e-4, 2e-5)
+    _close(out["rel_preds"].detach(), g["rel_preds"], 1e-4, 2e-5)
+    _close(out["act_preds"].detach(), g["act_preds"], 1e-4, 2e-5)
+    _close(out["memory"].detach()[:, ::8, ::16], g["memory_sl"], 1e-4, 2e-5)
+    _close(out["lang_pre_x"].detach()[:, :, ::8], g["lang_pre_x_sl"], 1e-4, 2e-5)
+    losses = shg_ref.hgqa_losses(out, batch, cfg)
+    for key, per in (("rel", cfg.num_rel), ("act", cfg.num_act)):
+        q, t = g[f"{key}_q"], g[f"{key}_t"]
+        for n, (qi, ti) in enumerate(losses[f"{key}_idx"]):
+            k = len(qi)
+            assert np.array_equal(qi.numpy(), q[n, :k]) and np.array_equal(ti.numpy(), t[n, :k]), (key, n)
+            assert (q[n, k:] == -1).all()
+        assert np.array_equal(losses[f"{key}_grid"].numpy(), g[f"{key}_grid"])
+    for k in ("bce", "rel_ce", "act_ce", "total", "rel_err", "act_err"):
+        _close(losses[k].detach(), g[k], 1e-4, 1e-4)
+    names = list(p)
+    grads = torch.autograd.grad(losses["total"], [p[k] for k in names], allow_unused=True)
+    got = {k: gr for k, gr in zip(names, grads) if gr is not None}
+    ref_names = [str(x) for x in g["grad_names"]]
+    assert set(got) == set(ref_names)
+    for i, k in enumerate(ref_names):
+        n_ref = g["grad_norms"][i]
+        n_got = float(got[k].double().norm())
+        assert abs(n_got - n_ref) <= 2e-3 * max(n_ref, 1e-6) + 1e-7, (k, n_got, n_ref)
+        _close(got[k].reshape(-1)[:4], g["grad_heads"][i], 5e-3, 1e-6 + 1e-4 * n_ref)
+    tot = float(torch.sqrt(sum((x.double() ** 2).sum() for x in got.values())))
+    assert abs(tot - float(g["grad_total_norm"])) <= 1e-3 * float(g["grad_total_norm"])
+
+
+def test_q_only_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "agqa_q_b4.npz"))
+    cfg = shg_ref.Cfg(llayers=2, task="q")
+    p = shg_ref.det_params(cfg)
+    assert set(p) <= set(str(x) for x in g["param_names"])
+    batch = shg_ref.synthetic_batch(int(g["batch_size"]), cfg, seed=int(g["batch_seed"]), with_feat=False)
+    out = shg_ref.agqa_forward(p, cfg, batch)
+    _close(out["logit"], g["logit"], 1e-4, 2e-5)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out["logit"], batch["target"]) * cfg.num_answers
+    _close(loss, g["loss"], 1e-5, 1e-5)
+
+
+def test_bertadam_and_clip_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "bertadam_steps.npz"))
+    params = {str(i): torch.from_numpy(g[f"init{i}"].copy()) for i in range(3)}
+    state = {}
+    for s in range(4):
+        grads = {str(i): torch.from_numpy(g[f"grad{s}_{i}"].copy()) for i in range(3)}
+        norm = shg_ref.clip_grad_norm(list(grads.values()), 5.0)
+        assert abs(float(norm) - g["norms"][s]) < 1e-4 * g["norms"][s]
+        shg_ref.bertadam_step(params, grads, state, lr=1e-3, step=s, t_total=20)
+        for i in range(3):
+            _close(params[str(i)], g[f"after{s}_{i}"], 1e-6, 1e-7)
