@@ -1,0 +1,223 @@
+/* shg_vqa.h - C ABI of libshgvqa.so, the MI355X (gfx950) implementation of the SHG-VQA hot path.
+ *
+ * The reference (aurooj/SHG-VQA) is 100 % PyTorch eager and has no FFI of its own; its seam is the
+ * nn.Module API.  Each entry point below states which reference
+ * arithmetic it replaces (file:line under AGQA/src/).  The host side (the shg_vqa_amd python package) mirrors the
+ * reference's module interface and reaches these functions through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer owned by the caller
+ *     unless the comment says "host".  The library never allocates or frees device memory and holds
+ *     no mutable global state besides the last error string.
+ *   - Every function only enqueues work on `stream` (a hipStream_t passed as void*); it is safe to
+ *     call during hipGraph stream capture.
+ *   - Return value: 0 = ok, SHG_ERR_INVALID (<0) = bad argument (see shg_last_error_string()),
+ *     >0 = a hipError_t from the launch.
+ *   - dtype: SHG_F32 or SHG_BF16 selects the storage type of activations/operands.  Statistics
+ *     (mean/rstd/LSE), losses, optimiser state and master weights are always fp32.
+ *   - Matrices are row-major and contiguous unless a stride argument exists.
+ *   - Dropout masks are a pure function of (seed_state, stream_id, element index): `seed_state`
+ *     points to two uint64 {seed, step} in device memory (may be NULL when p == 0) so that a captured
+ *     graph gets fresh masks on every replay; `stream_id` separates call sites within a step.
+ */
+#ifndef SHG_VQA_H
+#define SHG_VQA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHG_F32 0
+#define SHG_BF16 1
+
+#define SHG_ERR_INVALID (-1)
+
+#define SHG_ACT_NONE 0
+#define SHG_ACT_GELU 1 /* erf form, modeling_capsbert.py:127-133 */
+#define SHG_ACT_RELU 2 /* transformer.py:195 (decoder FFN) */
+
+#define SHG_MASK_NONE 0
+#define SHG_MASK_KEY 1  /* additive fp32 [B, Sk]   (BERT (1-m)*-1e4 masks, modeling_capsbert.py:1826-1842) */
+#define SHG_MASK_FULL 2 /* additive fp32 [Sq, Sk]  (block-causal -inf/0 mask, entry.py:114-121) */
+
+int shg_version(void);
+const char* shg_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hungarian matcher, per-frame branch.
+ * Replaces HungarianMatcher.forward (lxrt/matcher.py:62-80) including the softmax, the
+ * out_prob[:, tgt_ids] gather, the .cpu() copy and the python loop over
+ * scipy.optimize.linear_sum_assignment; also builds the target-class grid of
+ * AGQA.loss_labels / get_target_classes (tasks/agqaHGQA.py:178-220).
+ *   logits     [n_frames, per_frame, n_classes]  (dtype)      per_frame <= 8
+ *   tgt        [n_frames, per_frame] int64, class ids of the frame's targets, first tgt_len[f] valid
+ *   tgt_len    [n_frames] int32 (0..per_frame)
+ *   out_query  [n_frames, per_frame] int64: matched query index within the frame, ascending, -1 padded
+ *   out_target [n_frames, per_frame] int64: matched target index within the frame, -1 padded
+ *   out_grid   [n_frames, per_frame] int64: class id for every query slot (background_class unless matched)
+ * Assignment indices are bit-identical to SciPy's (float64 JV solver with SciPy's tie rules).
+ */
+int shg_hungarian_per_frame(const void* logits, int dtype, int n_frames, int per_frame, int n_classes,
+                            const int64_t* tgt, const int32_t* tgt_len, int64_t background_class,
+                            int64_t* out_query, int64_t* out_target, int64_t* out_grid, void* stream);
+
+/* Same solver on explicit cost matrices (test entry point; lxrt/matcher.py:79).
+ *   cost [n, rows, cols_max] fp32, n_cols [n] int32 (<= cols_max <= 8, rows <= 8) */
+int shg_lsap_batched(const float* cost, int n, int rows, int cols_max, const int32_t* n_cols,
+                     int64_t* out_row, int64_t* out_col, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Set loss: class-weighted cross entropy over every query slot.
+ * Replaces F.cross_entropy(logits.transpose(1,2), grid, weight) in AGQA.loss_labels
+ * (tasks/agqaHGQA.py:223) and its backward.
+ *   fwd : row_stats [4, rows] fp32 = {lse[r]}, {w*nll[r]}, {w[r]}, {match flag};  sums[0..1] = {sum w*nll, sum w}
+ *         (deterministic two-stage reduction), sums[2] = #rows whose arg-max equals a non-background
+ *         target, sums[3] = #rows with a non-background target (for class_error, agqaHGQA.py:228).
+ *   loss = sums[0]/sums[1] is formed by the caller (after an all-reduce of `sums` under data parallel).
+ *   bwd : dlogits[r,c] = gscale[0] * w[t_r] * (softmax(r)[c] - [c==t_r]) / sums[1]   (gscale NULL => 1);
+ *         dlogits rows are ldd >= n_classes elements apart and columns n_classes..ldd-1 are zeroed, so the
+ *         buffer can feed shg_gemm directly (16-byte rows).
+ */
+int shg_weighted_ce_fwd(const void* logits, int dtype, int64_t rows, int n_classes, const int64_t* target,
+                        const float* class_weight, int64_t background_class, float* row_stats, float* sums,
+                        void* stream);
+int shg_weighted_ce_bwd(const void* logits, int dtype, int64_t rows, int n_classes, const int64_t* target,
+                        const float* class_weight, const float* row_stats, const float* sums,
+                        const float* gscale, void* dlogits, int64_t ldd, void* stream);
+
+/* BCEWithLogitsLoss(mean) * n_classes  (tasks/agqaHGQA.py:344-345).
+ *   loss[0] = n_classes * mean(bce);  dlogits = gscale[0] * (sigmoid(x) - y) / rows            */
+int shg_bce_logits_fwd_bwd(const void* logits, int dtype, int64_t rows, int n_classes, const float* target,
+                           const float* gscale, float* loss, void* dlogits, int64_t ldd, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused epilogues.
+ * y = act(x + bias), optional dropout.  Replaces BertIntermediate's bias+erf-GELU
+ * (modeling_capsbert.py:472-475) and the decoder FFN's bias+ReLU+dropout (transformer.py:230).
+ *   x, y [rows, cols] (dtype); bias [cols] fp32 or NULL.  bwd: dx = dy * act'(x+bias) * keep/(1-p),
+ *   dbias_partial [n_partials, cols] fp32 (column sums of dx per row-chunk; reduce with shg_colsum_finish).
+ */
+int shg_bias_act_fwd(const void* x, const float* bias, void* y, int dtype, int64_t rows, int cols, int act,
+                     float p_drop, const uint64_t* seed_state, uint64_t stream_id, void* stream);
+int shg_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial,
+                     int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
+                     const uint64_t* seed_state, uint64_t stream_id, void* stream);
+
+/* z = dropout(act(x + bias)) + residual;  y = LayerNorm(z) * gamma + beta.
+ * Replaces BertAttOutput / BertOutput (modeling_capsbert.py:431-435, :485-489), the decoder's
+ * residual+norm{1,2,3} (transformer.py:220-232), the MLP heads' GELU+LayerNorm
+ * (tasks/agqa_model.py:105-110) and the LayerNorm of the embedding blocks (modeling_capsbert.py:322, :353).
+ *   x [rows, cols] (dtype); bias [cols] fp32 or NULL; residual [rows, cols] (dtype) or NULL
+ *   y [rows, cols] (dtype); z_out [rows, cols] (dtype) or NULL (pre-norm sum, needed by bwd);
+ *   mean, rstd [rows] fp32.  cols <= 4096, cols % 8 == 0.
+ * bwd: given dy and z (as saved), produces dz-style gradients:
+ *   dres (may be NULL) = dz;  dx = dz * keep/(1-p) * act'(x+bias)  (x needed only when act != NONE)
+ *   dgamma_partial/dbeta_partial/dbias_partial [n_partials, cols] fp32.
+ */
+int shg_bias_act_drop_res_ln_fwd(const void* x, const float* bias, const void* residual, const float* gamma,
+                                 const float* beta, void* y, void* z_out, float* mean, float* rstd, int dtype,
+                                 int64_t rows, int cols, int act, float eps, float p_drop,
+                                 const uint64_t* seed_state, uint64_t stream_id, void* stream);
+int shg_bias_act_drop_res_ln_bwd(const void* dy, const void* z, const void* x, const float* bias,
+                                 const float* gamma, const float* mean, const float* rstd, void* dx, void* dres,
+                                 float* dgamma_partial, float* dbeta_partial, float* dbias_partial,
+                                 int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
+                                 const uint64_t* seed_state, uint64_t stream_id, void* stream);
+/* partial[p, c] = sum over the p-th row chunk of x[r, c]  (x rows ld elements apart; bias gradient of a GEMM
+ * whose bias is added in its epilogue, e.g. the Q/K/V projections modeling_capsbert.py:373-375) */
+int shg_colsum_partial(const void* x, int dtype, int64_t rows, int cols, int64_t ld, float* partial, int n_partials,
+                       void* stream);
+/* out[c] (+)= sum_p partial[p, c]   (deterministic second stage of the column reductions) */
+int shg_colsum_finish(const float* partial, int n_partials, int cols, float* out, int accumulate, void* stream);
+/* number of row-chunks (n_partials) the bwd kernels use for `rows` */
+int shg_colsum_partials(int64_t rows);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused multi-head attention, head dim 64.
+ * O = dropout(softmax(scale * Q K^T + mask)) V, never materialising the [B,H,Sq,Sk] scores.
+ * Replaces BertAttention.forward's scores/softmax/dropout/context (modeling_capsbert.py:394-421)
+ * and the core of nn.MultiheadAttention in the DETR decoder (transformer.py:219-229).
+ *   q [B, Sq, H, 64] addressed as q + b*q_bstride + s*q_sstride + h*64 (strides in elements), same for k, v;
+ *   o [B, Sq, H*64] contiguous; lse [B, H, Sq] fp32 (log-sum-exp of the scaled, masked scores).
+ *   mask: SHG_MASK_KEY -> fp32 [B, Sk]; SHG_MASK_FULL -> fp32 [Sq, Sk]; -inf allowed.
+ * bwd recomputes the probabilities from lse; delta [B,H,Sq] fp32 is workspace.
+ */
+int shg_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H,
+                      int Sq, int Sk, int64_t q_bstride, int64_t q_sstride, int64_t k_bstride, int64_t k_sstride,
+                      int64_t v_bstride, int64_t v_sstride, int mask_kind, const float* mask, float scale,
+                      float p_drop, const uint64_t* seed_state, uint64_t stream_id, void* stream);
+int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                      const float* lse, float* delta, void* dq, void* dk, void* dv, int dtype, int B, int H,
+                      int Sq, int Sk, int64_t q_bstride, int64_t q_sstride, int64_t k_bstride, int64_t k_sstride,
+                      int64_t v_bstride, int64_t v_sstride, int64_t dq_bstride, int64_t dq_sstride,
+                      int64_t dk_bstride, int64_t dk_sstride, int64_t dv_bstride, int64_t dv_sstride,
+                      int mask_kind, const float* mask, float scale, float p_drop, const uint64_t* seed_state,
+                      uint64_t stream_id, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM on the matrix cores:  C[M,N] = A . B (+ bias[N]), fp32 accumulation.
+ * Replaces the nn.Linear GEMMs of the path (modeling_capsbert.py:373-375, :427, :466, :481;
+ * transformer.py:192-196) and their backward.
+ *   Rows are read in 16-byte chunks: lda/ldb must be multiples of the chunk and cover the contiguous extent
+ *   rounded up to it; padding elements must be finite.
+ *   a_kmajor = 1: A stored [M, K] (lda = row stride);  0: A stored [K, M]
+ *   b_kmajor = 1: B stored [N, K] (ldb = row stride);  0: B stored [K, N]
+ *   C (dtype_c: SHG_F32 or SHG_BF16) row stride ldc; accumulate != 0 adds into C (fp32 C only).
+ *   forward  y = x W^T : a_kmajor=1 (x), b_kmajor=1 (W [N,K])
+ *   dgrad   dx = dy W  : a_kmajor=1 (dy [M,N]), b_kmajor=0 (W [N,K] read as [Kred=N][K])
+ *   wgrad   dW = dy^T x: a_kmajor=0 (dy [M,N] as [Kred=M][N]), b_kmajor=0 (x [M,K] as [Kred=M][K])
+ */
+int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
+             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
+             int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv3d with kernel (5,3,3), "valid" in T, zero padding 1 in H and W, as an implicit GEMM over a
+ * channels-last input.  Replaces ZeroPad2d(1) -> nn.Conv3d(k=(5,3,3)) -> GeLU of
+ * VisualFeatEncoder (modeling_capsbert.py:991-996).
+ *   x  [B, T, H+2, W+2, Cin]   (dtype) channels-last, spatially pre-padded with zeros
+ *   w  [Cout, 5, 3, 3, Cin]    (dtype) = the reference weight [Cout,Cin,5,3,3] permuted
+ *   y  [B, T-4, H, W, Cout]    (dtype_y), y = act(conv + bias); if pad_out != 0 y is written into a
+ *      spatially padded [B, T-4, H+2, W+2, Cout] buffer (border untouched, must be pre-zeroed)
+ *   wgrad: dw [Cout,5,3,3,Cin] fp32 (+= when accumulate), dy [B,T-4,H,W,Cout] (dtype)
+ *   The input gradient is the same forward kernel applied to dy zero-padded by 4 in T and 1 in H/W
+ *   with the weight flipped and transposed ([Cin][4-kt][2-kh][2-kw][Cout]); the host does that
+ *   re-layout (shg_vqa_amd/ops.py).
+ *   workspace: shg_conv3d_k533_workspace_bytes(B,T,H,W) bytes, filled once per shape by
+ *   shg_conv3d_k533_prepare (gather tables: position of every output row in the padded tensors).
+ */
+int64_t shg_conv3d_k533_workspace_bytes(int B, int T, int H, int W);
+int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int W, void* stream);
+int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T, int H,
+                        int W, int Cin, int Cout, int act, int pad_out, const void* workspace, void* stream);
+int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
+                          int Cin, int Cout, int accumulate, const void* workspace, void* stream);
+/* NCDHW fp32 features -> channels-last, spatially zero-padded (dtype) : [B,C,T,H,W] -> [B,T,H+2,W+2,C] */
+int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int T, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser on a flat parameter arena.
+ * Replaces nn.utils.clip_grad_norm_(params, max_norm) + BertAdam.step (tasks/agqaHGQA.py:391-392;
+ * lxrt/optimization.py:101-180): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * u = m/(sqrt(v)+eps) + wd*p; p -= lr * sched(step/t_total) * u, no bias correction, where g is the
+ * gradient scaled by clip = min(max_norm/(norm+1e-6), 1).
+ *   shg_sumsq: partial[blocks] -> norm_sq[0] (fp32 accumulate in fp64 inside) of grad[0..n)
+ *   state: step_state[0] = number of updates already applied (int64, device); incremented by the kernel.
+ *   shadow (may be NULL): bf16 copy of the updated parameters, written in the same pass.
+ */
+int shg_sumsq(const float* x, int64_t n, double* partial, int n_partial, float* out_norm, void* stream);
+int shg_bertadam_arena(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+                       const float* grad_norm, float max_norm, float lr, float warmup, int64_t t_total,
+                       float b1, float b2, float eps, float weight_decay, int64_t* step_state, int bump_step,
+                       void* stream);
+/* *p += delta (single-thread kernel; keeps step / dropout counters on the device so a captured graph advances them) */
+int shg_add_i64(int64_t* p, int64_t delta, void* stream);
+/* dst(dtype) = cast(src fp32), n elements */
+int shg_cast_f32(const float* src, void* dst, int dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHG_VQA_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libshgvqa.so (include/shg_vqa.h).  No torch types cross this boundary:
+tensors are handed over as raw device pointers + sizes, the stream as a void*.
+
+The product never falls back to anything else: if the shared library is missing or a call
+fails, this module raises."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libshgvqa.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+MASK_NONE, MASK_KEY, MASK_FULL = 0, 1, 2
+
+P, I, L, F, U = c_void_p, c_int, c_int64, c_float, c_uint64
+
+_SIGNATURES = {
+    "shg_version": ([], c_int),
+    "shg_last_error_string": ([], c_char_p),
+    "shg_hungarian_per_frame": ([P, I, I, I, I, P, P, L, P, P, P, P], c_int),
+    "shg_lsap_batched": ([P, I, I, I, P, P, P, P], c_int),
+    "shg_weighted_ce_fwd": ([P, I, L, I, P, P, L, P, P, P], c_int),
+    "shg_weighted_ce_bwd": ([P, I, L, I, P, P, P, P, P, P, L, P], c_int),
+    "shg_bce_logits_fwd_bwd": ([P, I, L, I, P, P, P, P, L, P], c_int),
+    "shg_bias_act_fwd": ([P, P, P, I, L, I, I, F, P, U, P], c_int),
+    "shg_bias_act_bwd": ([P, P, P, P, P, I, I, L, I, I, F, P, U, P], c_int),
+    "shg_bias_act_drop_res_ln_fwd": ([P, P, P, P, P, P, P, P, P, I, L, I, I, F, F, P, U, P], c_int),
+    "shg_bias_act_drop_res_ln_bwd": ([P, P, P, P, P, P, P, P, P, P, P, P, I, I, L, I, I, F, P, U, P], c_int),
+    "shg_colsum_partial": ([P, I, L, I, L, P, I, P], c_int),
+    "shg_colsum_finish": ([P, I, I, P, I, P], c_int),
+    "shg_colsum_partials": ([L], c_int),
+    "shg_attention_fwd": ([P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, I, P, F, F, P, U, P], c_int),
+    "shg_attention_bwd": ([P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, L,
+                           I, P, F, F, P, U, P], c_int),
+    "shg_gemm": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P], c_int),
+    "shg_conv3d_k533_workspace_bytes": ([I, I, I, I], c_int64),
+    "shg_conv3d_k533_prepare": ([P, I, I, I, I, P], c_int),
+    "shg_conv3d_k533_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P], c_int),
+    "shg_conv3d_k533_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, P, P], c_int),
+    "shg_ncdhw_to_padded_cl": ([P, P, I, I, I, I, I, I, P], c_int),
+    "shg_sumsq": ([P, L, P, I, P, P], c_int),
+    "shg_bertadam_arena": ([P, P, P, P, P, L, P, F, F, F, L, F, F, F, F, P, I, P], c_int),
+    "shg_add_i64": ([P, L, P], c_int),
+    "shg_cast_f32": ([P, P, I, L, P], c_int),
+}
+
+_lib = None
+
+
+class ShgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ShgError("libshgvqa.so is missing: run `python -m shg_vqa_amd.build` (or __graft_entry__.build())")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (args, ret) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = ret
+        _lib = handle
+    return _lib
+
+
+def exported_names():
+    return sorted(_SIGNATURES)
+
+
+def call(name, *args):
+    """Calls an int-returning entry point and raises ShgError on a non-zero status."""
+    fn = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        msg = lib().shg_last_error_string()
+        raise ShgError("%s failed (rc=%d): %s" % (name, rc, msg.decode() if msg else ""))
+    return rc

@@ -1,0 +1,111 @@
+// Shared device helpers for the SHG-VQA gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/shg_vqa.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define SHG_WAVE 64
+
+namespace shg {
+
+// ------------------------------------------------------------------ error plumbing
+void set_error(const char* msg);
+int fail_arg(const char* msg);           // records msg, returns SHG_ERR_INVALID
+int check_launch(const char* what);      // hipGetLastError -> 0 or positive hipError_t
+
+// ------------------------------------------------------------------ scalar conversion
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of T
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+
+// ------------------------------------------------------------------ wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ counter-based dropout RNG
+// keep(element) is a pure function of (seed, stream, element index) so that backward kernels
+// regenerate the forward mask.  Two rounds of a 64->32 bit mix (splitmix-style).
+__device__ __forceinline__ uint32_t mix_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 16);
+}
+// threshold = (uint32_t)(p * 2^32); keep iff mix >= threshold
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t threshold) {
+    return mix_u32(seed, idx) >= threshold;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0.0) return 0u;
+    if (t >= 4294967295.0) return 4294967295u;
+    return (uint32_t)t;
+}
+
+// The per-step dropout seed lives in device memory so that a captured hipGraph replays with fresh
+// masks: kernels read seed_state[0] (seed) + seed_state[1] (step counter), and `stream_id`
+// separates the call sites inside one step.
+__device__ __forceinline__ uint64_t dropout_seed(const uint64_t* seed_state, uint64_t stream_id) {
+    uint64_t s = seed_state ? (seed_state[0] + 0x632BE59BD9B4E019ull * (seed_state[1] + 1)) : 0x1234567ull;
+    return s ^ (stream_id * 0xD1342543DE82EF95ull);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+}  // namespace shg

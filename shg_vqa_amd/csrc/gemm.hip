@@ -1,0 +1,428 @@
+// Matrix-core GEMM family for gfx950: plain GEMM (all four operand layouts) and the implicit-GEMM
+// (5,3,3) Conv3d forward / weight-gradient kernels over a channels-last, spatially padded input.
+//
+// Structure (one kernel template, specialised by operand "sources"):
+//   * workgroup = 256 threads (4 waves, 2 x 2), output tile 128 x 128, K step 64;
+//   * both operands are staged global -> registers -> LDS with 16-byte accesses (issue the loads of
+//     tile t+1 before the MFMAs of tile t, write them to LDS after: one LDS buffer, global latency
+//     hidden behind the matrix work) into XOR-swizzled 64 x 64 sub-tiles (mma.h);
+//   * an operand stored with the contraction index contiguous is read with ds_read_b128 row
+//     fragments; one stored with the contraction index strided (dgrad / wgrad operands) is read
+//     with the transposing LDS read, so no transposed copy of weights or activations is ever made;
+//   * each wave owns 64 x 64 of the output as 4 x 4 accumulators of 16 x 16; the MFMA is issued
+//     as (B-fragment, A-fragment) so that a lane ends up with 4 consecutive n of one output row and
+//     stores them as one 8/16-byte vector;
+//   * fp32 accumulation always; bf16 or exact-fp32 operands (mma.h).
+// The convolution never materialises im2col: row r of the A tile is output position (b,t,h,w), the
+// K index runs over (tap, channel) and the gather is a per-row base offset (precomputed table) plus
+// a per-K-step tap offset - every 128-byte row piece is a contiguous, coalesced read of the
+// channels-last tensor.
+#include <math.h>
+
+#include "mma.h"
+
+namespace shg {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+template <typename T> struct Stage {
+    static constexpr int NCH = (128 * 64 * (int)sizeof(T)) / 16 / 256;   // 16-byte chunks per thread per operand
+};
+
+// Decomposes a thread's i-th staged chunk into (sub-tile, row, chunk-in-row).
+template <typename T> __device__ __forceinline__ void chunk_coord(int tid, int i, int& t, int& row, int& ch) {
+    using TL = Tile64<T>;
+    const int c = tid + 256 * i;
+    t = c / (64 * TL::CH);
+    const int w = c % (64 * TL::CH);
+    row = w / TL::CH;
+    ch = w % TL::CH;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operand sources
+// ---------------------------------------------------------------------------------------------
+// Plain matrix.  KMAJOR: stored [R][K] (row stride ld); otherwise stored [K][R].
+template <typename T, bool KMAJ> struct PlainSrc {
+    static constexpr bool KMAJOR = KMAJ;
+    const T* p;
+    int64_t ld, r0, R, K;
+    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
+        constexpr int EPC = Tile64<T>::EPC;
+        if (KMAJ) {
+            const int64_t gr = r0 + 64 * t + row, k = k0 + ch * EPC;
+            ok = gr < R && k < K;
+            return p + gr * ld + k;
+        } else {
+            const int64_t k = k0 + row, c = r0 + 64 * t + ch * EPC;
+            ok = k < K && c < R;
+            return p + k * ld + c;
+        }
+    }
+};
+
+struct ConvGeom {
+    int Cin, Hp, Wp;          // padded input plane
+};
+__device__ __forceinline__ int64_t tap_offset(const ConvGeom& g, int tap) {
+    const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+    return ((int64_t)(kt * g.Hp + kh) * g.Wp + kw) * g.Cin;
+}
+
+// A operand of the conv forward: rows = output positions (gathered), K = (tap, channel), K contiguous.
+template <typename T> struct ConvRowSrc {
+    static constexpr bool KMAJOR = true;
+    const T* x;
+    const int32_t* pos;       // [M] padded-input position index of output position m (tap 0)
+    int64_t r0, M;
+    ConvGeom g;
+    int64_t base[Stage<T>::NCH];
+    bool okr[Stage<T>::NCH];
+    __device__ __forceinline__ void prepare(int tid) {
+#pragma unroll
+        for (int i = 0; i < Stage<T>::NCH; ++i) {
+            int t, row, ch;
+            chunk_coord<T>(tid, i, t, row, ch);
+            const int64_t m = r0 + 64 * t + row;
+            okr[i] = m < M;
+            base[i] = okr[i] ? (int64_t)pos[m] * g.Cin + ch * Tile64<T>::EPC : 0;
+        }
+    }
+    __device__ __forceinline__ const T* addr(int i, int, int, int, int64_t k0, bool& ok) const {
+        const int tap = (int)(k0 / g.Cin);
+        ok = okr[i];
+        return x + base[i] + tap_offset(g, tap) + (k0 % g.Cin);
+    }
+};
+
+// B operand of the conv weight gradient: rows = reduction index (output positions, gathered),
+// columns = (tap, channel).  Stored with the contraction index strided.
+template <typename T> struct ConvColSrc {
+    static constexpr bool KMAJOR = false;
+    const T* x;
+    const int32_t* pos;
+    int64_t r0, R, K;         // r0: first (tap, channel) column of this block; R = 45 * Cin; K = M
+    ConvGeom g;
+    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
+        const int64_t m = k0 + row;
+        const int64_t c = r0 + 64 * t + ch * Tile64<T>::EPC;
+        ok = m < K && c < R;
+        const int64_t mm = ok ? m : 0;
+        const int tap = (int)(c / g.Cin);
+        return x + (int64_t)pos[mm] * g.Cin + tap_offset(g, tap) + (c % g.Cin);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// epilogue description
+// ---------------------------------------------------------------------------------------------
+template <typename TC> struct Epilogue {
+    TC* c;
+    int64_t ldc;
+    const float* bias;        // [N] or null
+    const int32_t* crow;      // optional output-row remap (conv into a padded buffer): row m -> crow[m]
+    int act;
+    int accumulate;
+    int vec_ok;               // ldc and base pointer allow vector stores of 4 elements
+};
+
+template <typename TC> __device__ __forceinline__ void store4(TC* p, const float (&v)[4], int n_valid, int vec_ok, int accumulate);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4], int n_valid, int vec_ok, int accumulate) {
+    if (n_valid == 4 && vec_ok) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        if (accumulate) o += *reinterpret_cast<f32x4*>(p);
+        *reinterpret_cast<f32x4*>(p) = o;
+    } else {
+        for (int r = 0; r < n_valid; ++r) p[r] = accumulate ? p[r] + v[r] : v[r];
+    }
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4], int n_valid, int vec_ok, int) {
+    if (n_valid == 4 && vec_ok) {
+        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(p) = o;
+    } else {
+        for (int r = 0; r < n_valid; ++r) p[r] = (bf16_t)v[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TC, typename SrcA, typename SrcB>
+__global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
+                                                   int grid_m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using TL = Tile64<T>;
+    constexpr int NCH = Stage<T>::NCH;
+    char* ldsA = smem;                       // two Tile64
+    char* ldsB = smem + 2 * TL::BYTES;       // two Tile64
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wr = wave >> 1, wc = wave & 1;
+    // consecutive workgroups walk M first so that blocks sharing a B (weight) panel are neighbours
+    const int64_t bm = blockIdx.x % grid_m, bn = blockIdx.x / grid_m;
+    const int64_t m0 = bm * BM, n0 = bn * BN;
+    sa.r0 = m0;
+    sb.r0 = n0;
+    sa.prepare(tid);
+    sb.prepare(tid);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[NCH], rb[NCH];
+    auto fetch = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int t, row, ch;
+            chunk_coord<T>(tid, i, t, row, ch);
+            bool oka, okb;
+            const T* pa = sa.addr(i, t, row, ch, k0, oka);
+            const T* pb = sb.addr(i, t, row, ch, k0, okb);
+            ra[i] = oka ? *reinterpret_cast<const uint4*>(pa) : make_uint4(0, 0, 0, 0);
+            rb[i] = okb ? *reinterpret_cast<const uint4*>(pb) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int t, row, ch;
+            chunk_coord<T>(tid, i, t, row, ch);
+            *reinterpret_cast<uint4*>(ldsA + t * TL::BYTES + TL::chunk_off(row, ch)) = ra[i];
+            *reinterpret_cast<uint4*>(ldsB + t * TL::BYTES + TL::chunk_off(row, ch)) = rb[i];
+        }
+    };
+
+    const int64_t nk = (K + BK - 1) / BK;
+    fetch(0);
+    commit();
+    __syncthreads();
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fetch((kt + 1) * BK);
+        const char* tA = ldsA + wr * TL::BYTES;
+        const char* tB = ldsB + wc * TL::BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = SrcA::KMAJOR ? lds_row_frag<T>(tA, 16 * i + li, 32 * ks, g) : lds_col_frag_nat<T>(tA, 32 * ks, 16 * i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[j] = SrcB::KMAJOR ? lds_row_frag<T>(tB, 16 * j + li, 32 * ks, g) : lds_col_frag_nat<T>(tB, 32 * ks, 16 * j, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma(acc[i][j], fb[j], fa[i]);   // rows = n, cols = m
+        }
+        __syncthreads();
+        if (kt + 1 < nk) commit();
+        __syncthreads();
+    }
+
+    // epilogue: lane holds, for output row m = .. + li, the 4 consecutive columns n = .. + 4g + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + 64 * wr + 16 * i + li;
+        if (m >= M) continue;
+        const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
+        TC* crowp = ep.c + crow * ep.ldc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + 64 * wc + 16 * j + 4 * g;
+            if (n >= N) continue;
+            const int nv = (int)min((int64_t)4, N - n);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r];
+                if (ep.bias && r < nv) x += ep.bias[n + r];
+                if (ep.act == SHG_ACT_GELU) x = gelu_erf(x);
+                else if (ep.act == SHG_ACT_RELU) x = fmaxf(x, 0.f);
+                v[r] = x;
+            }
+            store4<TC>(crowp + n, v, nv, ep.vec_ok, ep.accumulate);
+        }
+    }
+}
+
+template <typename T, typename TC, typename SrcA, typename SrcB>
+static int launch_gemm(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what) {
+    const int64_t gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
+    if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
+    const size_t lds = 4 * Tile64<T>::BYTES;
+    hipLaunchKernelGGL((gemm_kernel<T, TC, SrcA, SrcB>), dim3((unsigned)(gm * gn)), dim3(256), lds, st, sa, sb, ep, M, N, K, (int)gm);
+    return check_launch(what);
+}
+
+template <typename T, typename TC>
+static int gemm_dispatch(const void* a, const void* b, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, int64_t lda,
+                         int64_t ldb, int a_kmajor, int b_kmajor, hipStream_t st) {
+    const T* A = (const T*)a;
+    const T* B = (const T*)b;
+    if (a_kmajor && b_kmajor)
+        return launch_gemm<T, TC>(PlainSrc<T, true>{A, lda, 0, M, K}, PlainSrc<T, true>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_nt");
+    if (a_kmajor && !b_kmajor)
+        return launch_gemm<T, TC>(PlainSrc<T, true>{A, lda, 0, M, K}, PlainSrc<T, false>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_nn");
+    if (!a_kmajor && b_kmajor)
+        return launch_gemm<T, TC>(PlainSrc<T, false>{A, lda, 0, M, K}, PlainSrc<T, true>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_tt");
+    return launch_gemm<T, TC>(PlainSrc<T, false>{A, lda, 0, M, K}, PlainSrc<T, false>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_tn");
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helper kernels of the conv path
+// ---------------------------------------------------------------------------------------------
+// pos_in[m]  = ((b*Tin + to)*Hp + h)*Wp + w         (tap (0,0,0) of output position m in the padded input)
+// pos_out[m] = ((b*To  + to)*Hp + h+1)*Wp + w+1      (where output m lives in a spatially padded output)
+__global__ void conv_pos_kernel(int32_t* pos_in, int32_t* pos_out, int B, int Tin, int To, int H, int W) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t M = (int64_t)B * To * H * W;
+    if (m >= M) return;
+    const int w = (int)(m % W), h = (int)((m / W) % H), to = (int)((m / ((int64_t)W * H)) % To), b = (int)(m / ((int64_t)W * H * To));
+    const int Hp = H + 2, Wp = W + 2;
+    pos_in[m] = (int32_t)((((int64_t)b * Tin + to) * Hp + h) * Wp + w);
+    pos_out[m] = (int32_t)((((int64_t)b * To + to) * Hp + h + 1) * Wp + w + 1);
+}
+
+// [B,C,T,H,W] fp32 -> [B,T,H+2,W+2,C] (T) with a zero border.  LDS-tiled transpose: a block moves a
+// 64(c) x 64(hw-chunk) tile so that both the reads (along hw) and the writes (along c) are coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void ncdhw_to_padded_cl_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C,
+                                                                 int Tn, int H, int W) {
+    __shared__ float tile[64][65];
+    const int HW = H * W;
+    const int bt = blockIdx.z;              // b * T + t
+    const int b = bt / Tn, t = bt % Tn;
+    const int c0 = blockIdx.y * 64, s0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, s = s0 + tx;
+        tile[r][tx] = (c < C && s < HW) ? x[(((int64_t)b * C + c) * Tn + t) * HW + s] : 0.f;
+    }
+    __syncthreads();
+    const int Hp = H + 2, Wp = W + 2;
+    for (int r = ty; r < 64; r += 4) {
+        const int s = s0 + r, c = c0 + tx;
+        if (s < HW && c < C) {
+            const int h = s / W, w = s % W;
+            y[((((int64_t)bt) * Hp + h + 1) * Wp + w + 1) * C + c] = from_f32<T>(tile[tx][r]);
+        }
+    }
+}
+
+}  // namespace shg
+
+using namespace shg;
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
+                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
+                        int accumulate, void* stream) {
+    if (!a || !b || !c) return fail_arg("gemm: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm: sizes must be positive");
+    if ((dtype_ab != SHG_F32 && dtype_ab != SHG_BF16) || (dtype_c != SHG_F32 && dtype_c != SHG_BF16)) return fail_arg("gemm: bad dtype");
+    if (dtype_ab == SHG_F32 && dtype_c == SHG_BF16) return fail_arg("gemm: fp32 operands need an fp32 C");
+    if (accumulate && dtype_c != SHG_F32) return fail_arg("gemm: accumulate needs an fp32 C");
+    const int epc = dtype_ab == SHG_BF16 ? 8 : 4;
+    if (!al16(a) || !al16(b)) return fail_arg("gemm: A and B must be 16-byte aligned");
+    if (lda % epc || ldb % epc) return fail_arg("gemm: lda/ldb must keep rows 16-byte aligned");
+    // operands are read in whole 16-byte chunks: a row's contiguous extent is rounded up to the chunk,
+    // so the row (lda/ldb) must reach that far and whatever sits in the padding must be finite
+    // (it only ever meets zero-filled data of the other operand).
+    const int64_t ea = ((a_kmajor ? K : M) + epc - 1) / epc * epc, eb = ((b_kmajor ? K : N) + epc - 1) / epc * epc;
+    if (lda < ea || ldb < eb || ldc < N) return fail_arg("gemm: leading dimension too small for 16-byte row reads");
+    hipStream_t st = (hipStream_t)stream;
+    const int celt = dtype_c == SHG_F32 ? 4 : 2;
+    const int vec_ok = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) % (4 * celt)) == 0);
+    if (dtype_c == SHG_F32) {
+        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, SHG_ACT_NONE, accumulate, vec_ok};
+        return dtype_ab == SHG_F32 ? gemm_dispatch<float, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st)
+                                   : gemm_dispatch<bf16_t, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
+    }
+    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, SHG_ACT_NONE, 0, vec_ok};
+    return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
+}
+
+extern "C" int64_t shg_conv3d_k533_workspace_bytes(int B, int T, int H, int W) {
+    if (B < 1 || T < 5 || H < 1 || W < 1) return -1;
+    const int64_t M = (int64_t)B * (T - 4) * H * W;
+    return 2 * ((M * 4 + 255) / 256) * 256;
+}
+
+static int conv_check(int dtype, int B, int T, int H, int W, int Cin, int Cout, const void* ws) {
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("conv3d: bad dtype");
+    if (B < 1 || T < 5 || H < 1 || W < 1) return fail_arg("conv3d: need T >= 5 and positive sizes");
+    if (Cin % 64 || Cout % 8) return fail_arg("conv3d: Cin must be a multiple of 64 and Cout of 8");
+    if ((int64_t)B * T * (H + 2) * (W + 2) > 0x7fffffff) return fail_arg("conv3d: position index overflows int32");
+    if (!ws || !al16(ws)) return fail_arg("conv3d: workspace missing or unaligned");
+    return 0;
+}
+
+extern "C" int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int W, void* stream) {
+    if (!workspace || B < 1 || T < 5 || H < 1 || W < 1) return fail_arg("conv3d_prepare: bad argument");
+    const int64_t M = (int64_t)B * (T - 4) * H * W;
+    int32_t* pos_in = (int32_t*)workspace;
+    int32_t* pos_out = (int32_t*)((char*)workspace + shg_conv3d_k533_workspace_bytes(B, T, H, W) / 2);
+    hipLaunchKernelGGL(conv_pos_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_in, pos_out, B, T, T - 4, H, W);
+    return check_launch("conv3d_prepare");
+}
+
+extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
+                                   int H, int W, int Cin, int Cout, int act, int pad_out, const void* workspace,
+                                   void* stream) {
+    if (!x || !w || !y) return fail_arg("conv3d_fwd: null pointer");
+    if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
+    if (!al16(x) || !al16(w) || !al16(y)) return fail_arg("conv3d_fwd: pointers must be 16-byte aligned");
+    const int64_t M = (int64_t)B * (T - 4) * H * W, N = Cout, K = (int64_t)45 * Cin;
+    const int32_t* pos_in = (const int32_t*)workspace;
+    const int32_t* pos_out = (const int32_t*)((const char*)workspace + shg_conv3d_k533_workspace_bytes(B, T, H, W) / 2);
+    ConvGeom g{Cin, H + 2, W + 2};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) {
+        ConvRowSrc<float> sa{(const float*)x, pos_in, 0, M, g};
+        PlainSrc<float, true> sb{(const float*)w, K, 0, N, K};
+        Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1};
+        return launch_gemm<float, float>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
+    }
+    ConvRowSrc<bf16_t> sa{(const bf16_t*)x, pos_in, 0, M, g};
+    PlainSrc<bf16_t, true> sb{(const bf16_t*)w, K, 0, N, K};
+    Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1};
+    return launch_gemm<bf16_t, bf16_t>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
+}
+
+extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
+                                     int Cin, int Cout, int accumulate, const void* workspace, void* stream) {
+    if (!x || !dy || !dw) return fail_arg("conv3d_wgrad: null pointer");
+    if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
+    if (!al16(x) || !al16(dy) || !al16(dw)) return fail_arg("conv3d_wgrad: pointers must be 16-byte aligned");
+    // dW[co][(tap, ci)] = sum_m dY[m][co] * Xgather[m][(tap, ci)] : GEMM with M' = Cout, N' = 45*Cin, K' = M
+    const int64_t Mo = (int64_t)B * (T - 4) * H * W, Ncols = (int64_t)45 * Cin;
+    const int32_t* pos_in = (const int32_t*)workspace;
+    ConvGeom g{Cin, H + 2, W + 2};
+    hipStream_t st = (hipStream_t)stream;
+    Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1};
+    if (dtype == SHG_F32) {
+        PlainSrc<float, false> sa{(const float*)dy, Cout, 0, Cout, Mo};
+        ConvColSrc<float> sb{(const float*)x, pos_in, 0, Ncols, Mo, g};
+        return launch_gemm<float, float>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+    }
+    PlainSrc<bf16_t, false> sa{(const bf16_t*)dy, Cout, 0, Cout, Mo};
+    ConvColSrc<bf16_t> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
+    return launch_gemm<bf16_t, float>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+}
+
+extern "C" int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int T, int H, int W, void* stream) {
+    if (!x || !y) return fail_arg("ncdhw_to_padded_cl: null pointer");
+    if (B < 1 || C < 1 || T < 1 || H < 1 || W < 1 || (int64_t)B * T > 65535) return fail_arg("ncdhw_to_padded_cl: bad sizes");
+    dim3 grid((H * W + 63) / 64, (C + 63) / 64, B * T), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) hipLaunchKernelGGL(ncdhw_to_padded_cl_kernel<float>, grid, block, 0, st, x, (float*)y, B, C, T, H, W);
+    else if (dtype == SHG_BF16) hipLaunchKernelGGL(ncdhw_to_padded_cl_kernel<bf16_t>, grid, block, 0, st, x, (bf16_t*)y, B, C, T, H, W);
+    else return fail_arg("ncdhw_to_padded_cl: bad dtype");
+    return check_launch("ncdhw_to_padded_cl");
+}

@@ -1,0 +1,203 @@
+// Per-frame Hungarian matcher on the GPU (replaces lxrt/matcher.py:62-80 + scipy LSAP).
+//
+// One wave handles FRAMES_PER_WAVE frame-problems.  Phase 1 (all 64 lanes): for every query row of
+// the wave's frames, a wave-cooperative softmax (coalesced row read, shuffle reductions) and the
+// gather of the target columns -> cost = -softmax[q, tgt_j] (fp32) into LDS as float64.
+// Phase 2 (one lane per problem): the shortest-augmenting-path solver with SciPy's scan order and
+// tie rules in float64 on its LDS slice, so the indices are bit-identical to
+// scipy.optimize.linear_sum_assignment.  Problems are at most 8x8: latency-bound, not HBM-bound
+// (reads 4096 x 457 logits = 7.5 MB per call).
+#include <math.h>
+
+#include "common.h"
+
+namespace shg {
+
+constexpr int HMAX = 8;             // max queries per frame / targets per frame
+constexpr int FRAMES_PER_WAVE = 8;
+
+struct LsapScratch {                // one problem, lives in LDS
+    double cost[HMAX * HMAX];       // solver orientation: [row = target][col = query]
+    double u[HMAX], v[HMAX], spc[HMAX];
+    int col4row[HMAX], row4col[HMAX], path[HMAX], remaining[HMAX];
+    unsigned char in_sr[HMAX], in_sc[HMAX];
+};
+
+// Solves the (n_tgt x n_q, n_tgt <= n_q) problem held in s.cost with leading dimension HMAX.
+// This is the "transposed" orientation SciPy uses when the matcher's (queries x targets) matrix has
+// more rows than columns.  On return s.col4row[t] = query assigned to target t.
+__device__ void lsap_wide(LsapScratch& s, int nr, int nc) {
+    for (int i = 0; i < nr; ++i) { s.u[i] = 0.0; s.col4row[i] = -1; }
+    for (int j = 0; j < nc; ++j) { s.v[j] = 0.0; s.row4col[j] = -1; }
+    for (int cur = 0; cur < nr; ++cur) {
+        double min_val = 0.0;
+        int i = cur, sink = -1, n_rem = nc;
+        for (int r = 0; r < nr; ++r) s.in_sr[r] = 0;
+        for (int j = 0; j < nc; ++j) { s.in_sc[j] = 0; s.spc[j] = INFINITY; s.path[j] = -1; s.remaining[j] = nc - 1 - j; }
+        while (sink == -1) {
+            int best = -1;
+            double lowest = INFINITY;
+            s.in_sr[i] = 1;
+            const double ui = s.u[i];
+            for (int it = 0; it < n_rem; ++it) {
+                const int j = s.remaining[it];
+                const double r = min_val + s.cost[i * HMAX + j] - ui - s.v[j];
+                double sj = s.spc[j];
+                if (r < sj) { s.path[j] = i; s.spc[j] = r; sj = r; }
+                if (sj < lowest || (sj == lowest && s.row4col[j] == -1)) { lowest = sj; best = it; }
+            }
+            min_val = lowest;
+            if (best < 0) return;   // cannot happen with finite costs
+            const int j = s.remaining[best];
+            if (s.row4col[j] == -1) sink = j; else i = s.row4col[j];
+            s.in_sc[j] = 1;
+            s.remaining[best] = s.remaining[--n_rem];
+        }
+        s.u[cur] += min_val;
+        for (int r = 0; r < nr; ++r)
+            if (s.in_sr[r] && r != cur) s.u[r] += min_val - s.spc[s.col4row[r]];
+        for (int j = 0; j < nc; ++j)
+            if (s.in_sc[j]) s.v[j] -= min_val - s.spc[j];
+        int j = sink;
+        for (;;) {
+            const int r = s.path[j];
+            s.row4col[j] = r;
+            const int prev = s.col4row[r];
+            s.col4row[r] = j;
+            j = prev;
+            if (r == cur) break;
+        }
+    }
+}
+
+// Writes the matcher's output convention for one frame: queries ascending with their targets.
+// rows = queries (R), cols = targets (n); SciPy solves the transpose when n < R and then orders by
+// query; when n == R it solves directly (rows = queries).
+__device__ void emit_assignment(LsapScratch& s, int R, int n, bool transposed, int64_t* out_q, int64_t* out_t) {
+    for (int k = 0; k < R; ++k) { out_q[k] = -1; out_t[k] = -1; }
+    if (n == 0) return;
+    if (!transposed) {           // solved with rows = queries: col4row[q] = target
+        for (int q = 0; q < R; ++q) { out_q[q] = q; out_t[q] = s.col4row[q]; }
+        return;
+    }
+    // col4row[t] = query; stable order by query index
+    int k = 0;
+    for (int q = 0; q < R; ++q)
+        for (int t = 0; t < n; ++t)
+            if (s.col4row[t] == q) { out_q[k] = q; out_t[k] = t; ++k; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void hungarian_per_frame_kernel(
+    const T* __restrict__ logits, int n_frames, int R, int C, const int64_t* __restrict__ tgt,
+    const int32_t* __restrict__ tgt_len, int64_t background, int64_t* __restrict__ out_q,
+    int64_t* __restrict__ out_t, int64_t* __restrict__ out_grid) {
+    __shared__ LsapScratch scratch[FRAMES_PER_WAVE];
+    const int lane = threadIdx.x;
+    const int f0 = blockIdx.x * FRAMES_PER_WAVE;
+
+    // phase 1: softmax statistics + gathered cost entries
+    for (int lf = 0; lf < FRAMES_PER_WAVE; ++lf) {
+        const int f = f0 + lf;
+        if (f >= n_frames) break;
+        const int n = min(max(tgt_len[f], 0), R);
+        if (n == 0) continue;
+        for (int q = 0; q < R; ++q) {
+            const T* row = logits + ((int64_t)f * R + q) * C;
+            float mx = -INFINITY;
+            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int c = lane; c < C; c += 64) sum += expf(to_f32(row[c]) - mx);
+            sum = wave_sum(sum);
+            if (lane < n) {
+                const int64_t cls = tgt[(int64_t)f * R + lane];
+                const float p = expf(to_f32(row[cls]) - mx) / sum;
+                const double cst = (double)(-p);
+                // n == R: solve with rows = queries; n < R: solve the transpose (rows = targets)
+                if (n == R) scratch[lf].cost[q * HMAX + lane] = cst;
+                else scratch[lf].cost[lane * HMAX + q] = cst;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: one lane per problem
+    if (lane < FRAMES_PER_WAVE) {
+        const int f = f0 + lane;
+        if (f < n_frames) {
+            const int n = min(max(tgt_len[f], 0), R);
+            LsapScratch& s = scratch[lane];
+            int64_t* oq = out_q + (int64_t)f * R;
+            int64_t* ot = out_t + (int64_t)f * R;
+            if (n > 0) {
+                if (n == R) lsap_wide(s, R, R); else lsap_wide(s, n, R);
+            }
+            emit_assignment(s, R, n, n != R, oq, ot);
+            if (out_grid) {
+                int64_t* g = out_grid + (int64_t)f * R;
+                for (int k = 0; k < R; ++k) g[k] = background;
+                for (int k = 0; k < n; ++k) g[oq[k]] = tgt[(int64_t)f * R + ot[k]];
+            }
+        }
+    }
+}
+
+// explicit-cost entry point: cost [n, rows, cols_max] fp32
+__global__ __launch_bounds__(64) void lsap_batched_kernel(const float* __restrict__ cost, int n_prob, int R,
+                                                          int cmax, const int32_t* __restrict__ n_cols,
+                                                          int64_t* __restrict__ out_r, int64_t* __restrict__ out_c) {
+    __shared__ LsapScratch scratch[FRAMES_PER_WAVE];
+    const int lane = threadIdx.x;
+    if (lane >= FRAMES_PER_WAVE) return;
+    const int p = blockIdx.x * FRAMES_PER_WAVE + lane;
+    if (p >= n_prob) return;
+    LsapScratch& s = scratch[lane];
+    const int n = min(max(n_cols[p], 0), cmax);
+    const float* c = cost + (int64_t)p * R * cmax;
+    const bool transposed = n < R;
+    for (int q = 0; q < R; ++q)
+        for (int t = 0; t < n; ++t) {
+            const double v = (double)c[q * cmax + t];
+            if (transposed) s.cost[t * HMAX + q] = v; else s.cost[q * HMAX + t] = v;
+        }
+    int64_t oq[HMAX], ot[HMAX];
+    if (n > 0) { if (transposed) lsap_wide(s, n, R); else lsap_wide(s, R, R); }
+    emit_assignment(s, R, n, transposed, oq, ot);
+    const int width = min(R, cmax);
+    for (int k = 0; k < width; ++k) { out_r[(int64_t)p * width + k] = oq[k]; out_c[(int64_t)p * width + k] = ot[k]; }
+}
+
+}  // namespace shg
+
+extern "C" int shg_hungarian_per_frame(const void* logits, int dtype, int n_frames, int per_frame, int n_classes,
+                                       const int64_t* tgt, const int32_t* tgt_len, int64_t background_class,
+                                       int64_t* out_query, int64_t* out_target, int64_t* out_grid, void* stream) {
+    using namespace shg;
+    if (!logits || !tgt || !tgt_len || !out_query || !out_target) return fail_arg("hungarian: null pointer");
+    if (per_frame < 1 || per_frame > HMAX) return fail_arg("hungarian: per_frame must be in [1,8]");
+    if (n_frames < 0 || n_classes < 1) return fail_arg("hungarian: bad sizes");
+    if (n_frames == 0) return 0;
+    dim3 grid((n_frames + FRAMES_PER_WAVE - 1) / FRAMES_PER_WAVE), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32)
+        hipLaunchKernelGGL(hungarian_per_frame_kernel<float>, grid, block, 0, st, (const float*)logits, n_frames,
+                           per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);
+    else if (dtype == SHG_BF16)
+        hipLaunchKernelGGL(hungarian_per_frame_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)logits, n_frames,
+                           per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);
+    else return fail_arg("hungarian: bad dtype");
+    return check_launch("hungarian_per_frame");
+}
+
+extern "C" int shg_lsap_batched(const float* cost, int n, int rows, int cols_max, const int32_t* n_cols,
+                                int64_t* out_row, int64_t* out_col, void* stream) {
+    using namespace shg;
+    if (!cost || !n_cols || !out_row || !out_col) return fail_arg("lsap: null pointer");
+    if (rows < 1 || rows > HMAX || cols_max < 1 || cols_max > HMAX || cols_max > rows)
+        return fail_arg("lsap: need 1 <= cols_max <= rows <= 8");
+    if (n <= 0) return n == 0 ? 0 : fail_arg("lsap: negative n");
+    dim3 grid((n + FRAMES_PER_WAVE - 1) / FRAMES_PER_WAVE), block(64);
+    hipLaunchKernelGGL(lsap_batched_kernel, grid, block, 0, (hipStream_t)stream, cost, n, rows, cols_max, n_cols,
+                       out_row, out_col);
+    return check_launch("lsap_batched");
+}

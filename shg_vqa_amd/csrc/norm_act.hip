@@ -1,0 +1,462 @@
+// Fused epilogue kernels: bias + activation + dropout + residual + LayerNorm (fwd/bwd), bias +
+// activation + dropout (fwd/bwd) and the deterministic second stage of their column reductions.
+// All of them are HBM-bound streaming kernels: one wave per row, 16-byte vector accesses, fp32
+// statistics via wave shuffles, no LDS in the forward path.
+#include <math.h>
+
+#include "common.h"
+
+namespace shg {
+
+constexpr int LN_MAX_CHUNKS = 8;        // 16-byte chunks per lane held in registers
+constexpr int ROWS_PER_PARTIAL = 32;    // rows folded into one partial row of the column sums
+constexpr int MAX_PARTIALS = 2048;
+
+__host__ inline int colsum_partials(int64_t rows) {
+    int64_t n = (rows + ROWS_PER_PARTIAL - 1) / ROWS_PER_PARTIAL;
+    if (n < 1) n = 1;
+    if (n > MAX_PARTIALS) n = MAX_PARTIALS;
+    return (int)n;
+}
+
+template <int ACT> __device__ __forceinline__ float act_fwd(float u) {
+    if (ACT == SHG_ACT_GELU) return gelu_erf(u);
+    if (ACT == SHG_ACT_RELU) return fmaxf(u, 0.f);
+    return u;
+}
+template <int ACT> __device__ __forceinline__ float act_grad(float u) {
+    if (ACT == SHG_ACT_GELU) return gelu_erf_grad(u);
+    if (ACT == SHG_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: one wave per row
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                     const T* __restrict__ residual, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     T* __restrict__ z_out, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out, int64_t rows, int cols, float eps,
+                                                     uint32_t drop_thr, float drop_scale,
+                                                     const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
+    constexpr int V = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = cols / V;
+    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
+    float zv[NCH][V];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            const int c0 = ch * V;
+            const int64_t off = row * cols + c0;
+            Vec16<T> xv = load16(x + off);
+            Vec16<T> rv;
+            if (residual) rv = load16(residual + off);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float u = xv.get(j) + (bias ? bias[c0 + j] : 0.f);
+                u = act_fwd<ACT>(u);
+                if (drop_thr) u = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? u * drop_scale : 0.f;
+                if (residual) u += rv.get(j);
+                zv[i][j] = u;
+                sum += u;
+            }
+            if (z_out) {
+                Vec16<T> zo;
+#pragma unroll
+                for (int j = 0; j < V; ++j) zo.set(j, zv[i][j]);
+                store16(z_out + off, zo);
+            }
+        }
+    }
+    // statistics are taken on the values as they are stored (rounded to T) so that the backward
+    // pass, which re-reads z_out, sees exactly the same normalised activations
+    if (z_out && sizeof(T) == 2) {
+        sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (lane + i * 64 < nchunk)
+#pragma unroll
+                for (int j = 0; j < V; ++j) { zv[i][j] = to_f32(from_f32<T>(zv[i][j])); sum += zv[i][j]; }
+    }
+    const float mean = wave_sum(sum) / (float)cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + i * 64 < nchunk)
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = zv[i][j] - mean; sq += d * d; }
+    const float var = wave_sum(sq) / (float)cols;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk) {
+            const int c0 = ch * V;
+            Vec16<T> yo;
+#pragma unroll
+            for (int j = 0; j < V; ++j) yo.set(j, (zv[i][j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j]);
+            store16(y + row * cols + c0, yo);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: block = 4 waves, loops over its chunk of rows; per-lane column partials in registers,
+// reduced across the 4 waves through LDS, one partial row per block.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                     const T* __restrict__ x, const float* __restrict__ bias,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     T* __restrict__ dres, float* __restrict__ dgamma_p,
+                                                     float* __restrict__ dbeta_p, float* __restrict__ dbias_p,
+                                                     int64_t rows, int cols, uint32_t drop_thr, float drop_scale,
+                                                     const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [3][4][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = cols / V;
+    const int nblk = gridDim.x;
+    const int64_t rows_per_blk = (rows + nblk - 1) / nblk;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r_end = min(rows, r_begin + rows_per_blk);
+    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
+
+    float ag[NCH][V], ab[NCH][V], abias[NCH][V];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < V; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; abias[i][j] = 0.f; }
+
+    for (int64_t row = r_begin + wave; row < r_end; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float gyv[NCH][V], xh[NCH][V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                const int c0 = ch * V;
+                const int64_t off = row * cols + c0;
+                Vec16<T> dv = load16(dy + off), zz = load16(z + off);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float g = dv.get(j);
+                    const float h = (zz.get(j) - mu) * rs;
+                    const float gy = g * gamma[c0 + j];
+                    xh[i][j] = h; gyv[i][j] = gy;
+                    s1 += gy; s2 += gy * h;
+                    ag[i][j] += g * h; ab[i][j] += g;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                const int c0 = ch * V;
+                const int64_t off = row * cols + c0;
+                Vec16<T> dzv, dxv, xv;
+                if (ACT != SHG_ACT_NONE) xv = load16(x + off);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float dz = rs * (gyv[i][j] - s1 - xh[i][j] * s2);
+                    dzv.set(j, dz);
+                    float d = dz;
+                    if (drop_thr) d = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? d * drop_scale : 0.f;
+                    if (ACT != SHG_ACT_NONE) d *= act_grad<ACT>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+                    dxv.set(j, d);
+                    abias[i][j] += to_f32(from_f32<T>(d));
+                }
+                if (dres) store16(dres + off, dzv);
+                if (dx) store16(dx + off, dxv);
+            }
+        }
+    }
+    // cross-wave reduction of the column partials
+    float* rg = red;
+    float* rb = red + 4 * cols;
+    float* rbi = red + 8 * cols;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                rg[wave * cols + ch * V + j] = ag[i][j];
+                rb[wave * cols + ch * V + j] = ab[i][j];
+                rbi[wave * cols + ch * V + j] = abias[i][j];
+            }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const int64_t o = (int64_t)blockIdx.x * cols + c;
+        if (dgamma_p) dgamma_p[o] = rg[c] + rg[cols + c] + rg[2 * cols + c] + rg[3 * cols + c];
+        if (dbeta_p) dbeta_p[o] = rb[c] + rb[cols + c] + rb[2 * cols + c] + rb[3 * cols + c];
+        if (dbias_p) dbias_p[o] = rbi[c] + rbi[cols + c] + rbi[2 * cols + c] + rbi[3 * cols + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bias + activation + dropout
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                           T* __restrict__ y, int64_t n_vec, int cols,
+                                                           uint32_t drop_thr, float drop_scale,
+                                                           const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
+    constexpr int V = Vec16<T>::N;
+    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t off = i * V;
+        const int c0 = (int)(off % cols);
+        Vec16<T> xv = load16(x + off), yv;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float u = act_fwd<ACT>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+            if (drop_thr) u = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? u * drop_scale : 0.f;
+            yv.set(j, u);
+        }
+        store16(y + off, yv);
+    }
+}
+
+template <typename T, int ACT, int NCH>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                           const T* __restrict__ dy, T* __restrict__ dx,
+                                                           float* __restrict__ dbias_p, int64_t rows, int cols,
+                                                           uint32_t drop_thr, float drop_scale,
+                                                           const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = cols / V;
+    const int nblk = gridDim.x;
+    const int64_t rows_per_blk = (rows + nblk - 1) / nblk;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r_end = min(rows, r_begin + rows_per_blk);
+    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
+    float ab[NCH][V];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < V; ++j) ab[i][j] = 0.f;
+    for (int64_t row = r_begin + wave; row < r_end; row += 4) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                const int c0 = ch * V;
+                const int64_t off = row * cols + c0;
+                Vec16<T> xv = load16(x + off), gv = load16(dy + off), dv;
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float d = gv.get(j);
+                    if (drop_thr) d = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? d * drop_scale : 0.f;
+                    d *= act_grad<ACT>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+                    dv.set(j, d);
+                    ab[i][j] += to_f32(from_f32<T>(d));
+                }
+                store16(dx + off, dv);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk)
+#pragma unroll
+            for (int j = 0; j < V; ++j) red[wave * cols + ch * V + j] = ab[i][j];
+    }
+    __syncthreads();
+    if (dbias_p)
+        for (int c = threadIdx.x; c < cols; c += 256)
+            dbias_p[(int64_t)blockIdx.x * cols + c] = red[c] + red[cols + c] + red[2 * cols + c] + red[3 * cols + c];
+}
+
+// column sums of a [rows, cols] activation (bias gradient of a GEMM whose bias sits in its epilogue)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                             int64_t rows, int cols, int64_t ld) {
+    const int nblk = gridDim.y;
+    const int64_t rows_per_blk = (rows + nblk - 1) / nblk;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_blk;
+    const int64_t r_end = min(rows, r_begin + rows_per_blk);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float acc = 0.f;
+    for (int64_t r = r_begin; r < r_end; ++r) acc += to_f32(x[r * ld + c]);
+    partial[(int64_t)blockIdx.y * cols + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int n_partials, int cols,
+                                                            float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int p = 0; p < n_partials; ++p) s += partial[(int64_t)p * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+template <typename T> static bool aligned16(const T* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+static int launch_ln_fwd(const void* x, const float* bias, const void* residual, const float* gamma, const float* beta,
+                         void* y, void* z_out, float* mean, float* rstd, int64_t rows, int cols, int act, float eps,
+                         float p_drop, const uint64_t* seed_state, uint64_t stream_id, hipStream_t st) {
+    const uint32_t thr = dropout_threshold(p_drop);
+    const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nch = (cols / Vec16<T>::N + 63) / 64;
+#define LN_FWD2(ACT, NCH)                                                                                             \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, ACT, NCH>), grid, block, 0, st, (const T*)x, bias, (const T*)residual, gamma, \
+                       beta, (T*)y, (T*)z_out, mean, rstd, rows, cols, eps, thr, scale, seed_state, stream_id)
+#define LN_FWD(ACT) do { if (nch <= 2) LN_FWD2(ACT, 2); else if (nch <= 4) LN_FWD2(ACT, 4); else LN_FWD2(ACT, 8); } while (0)
+    if (act == SHG_ACT_NONE) LN_FWD(SHG_ACT_NONE);
+    else if (act == SHG_ACT_GELU) LN_FWD(SHG_ACT_GELU);
+    else LN_FWD(SHG_ACT_RELU);
+#undef LN_FWD
+#undef LN_FWD2
+    return check_launch("bias_act_drop_res_ln_fwd");
+}
+
+template <typename T>
+static int launch_ln_bwd(const void* dy, const void* z, const void* x, const float* bias, const float* gamma,
+                         const float* mean, const float* rstd, void* dx, void* dres, float* dg, float* db, float* dbi,
+                         int n_partials, int64_t rows, int cols, int act, float p_drop, const uint64_t* seed_state,
+                         uint64_t stream_id, hipStream_t st) {
+    const uint32_t thr = dropout_threshold(p_drop);
+    const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    dim3 grid(n_partials), block(256);
+    const size_t lds = (size_t)12 * cols * sizeof(float);
+    const int nch = (cols / Vec16<T>::N + 63) / 64;
+#define LN_BWD2(ACT, NCH)                                                                                            \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, ACT, NCH>), grid, block, lds, st, (const T*)dy, (const T*)z, (const T*)x, bias, \
+                       gamma, mean, rstd, (T*)dx, (T*)dres, dg, db, dbi, rows, cols, thr, scale, seed_state, stream_id)
+#define LN_BWD(ACT) do { if (nch <= 2) LN_BWD2(ACT, 2); else if (nch <= 4) LN_BWD2(ACT, 4); else LN_BWD2(ACT, 8); } while (0)
+    if (act == SHG_ACT_NONE) LN_BWD(SHG_ACT_NONE);
+    else if (act == SHG_ACT_GELU) LN_BWD(SHG_ACT_GELU);
+    else LN_BWD(SHG_ACT_RELU);
+#undef LN_BWD
+#undef LN_BWD2
+    return check_launch("bias_act_drop_res_ln_bwd");
+}
+
+static int check_cols(int dtype, int cols, const char* who, int max_chunks = LN_MAX_CHUNKS) {
+    const int v = dtype == SHG_BF16 ? 8 : 4;
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("bad dtype");
+    if (cols <= 0 || cols % v != 0 || cols > 64 * max_chunks * v) return fail_arg(who);
+    return 0;
+}
+
+}  // namespace shg
+
+using namespace shg;
+
+extern "C" int shg_colsum_partials(int64_t rows) { return colsum_partials(rows); }
+
+extern "C" int shg_colsum_partial(const void* x, int dtype, int64_t rows, int cols, int64_t ld, float* partial,
+                                  int n_partials, void* stream) {
+    if (!x || !partial || rows <= 0 || cols <= 0 || ld < cols) return fail_arg("colsum_partial: bad argument");
+    if (n_partials < 1 || n_partials > MAX_PARTIALS) return fail_arg("colsum_partial: bad n_partials");
+    dim3 grid((cols + 255) / 256, n_partials), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, block, 0, st, (const float*)x, partial, rows, cols, ld);
+    else if (dtype == SHG_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, partial, rows, cols, ld);
+    else return fail_arg("colsum_partial: bad dtype");
+    return check_launch("colsum_partial");
+}
+
+extern "C" int shg_colsum_finish(const float* partial, int n_partials, int cols, float* out, int accumulate, void* stream) {
+    if (!partial || !out || n_partials < 1 || cols < 1) return fail_arg("colsum_finish: bad argument");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+                       n_partials, cols, out, accumulate);
+    return check_launch("colsum_finish");
+}
+
+extern "C" int shg_bias_act_drop_res_ln_fwd(const void* x, const float* bias, const void* residual, const float* gamma,
+                                            const float* beta, void* y, void* z_out, float* mean, float* rstd,
+                                            int dtype, int64_t rows, int cols, int act, float eps, float p_drop,
+                                            const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return fail_arg("ln_fwd: null pointer");
+    if (int e = check_cols(dtype, cols, "ln_fwd: cols must be a multiple of the 16-byte vector and <= 2048 (f32) / 4096 (bf16)")) return e;
+    if (!aligned16(x) || !aligned16(y) || (residual && !aligned16(residual)) || (z_out && !aligned16(z_out)))
+        return fail_arg("ln_fwd: pointers must be 16-byte aligned");
+    if (act < 0 || act > 2 || p_drop < 0.f || p_drop >= 1.f) return fail_arg("ln_fwd: bad act/p_drop");
+    if (rows <= 0) return rows == 0 ? 0 : fail_arg("ln_fwd: negative rows");
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == SHG_F32
+               ? launch_ln_fwd<float>(x, bias, residual, gamma, beta, y, z_out, mean, rstd, rows, cols, act, eps, p_drop, seed_state, stream_id, st)
+               : launch_ln_fwd<bf16_t>(x, bias, residual, gamma, beta, y, z_out, mean, rstd, rows, cols, act, eps, p_drop, seed_state, stream_id, st);
+}
+
+extern "C" int shg_bias_act_drop_res_ln_bwd(const void* dy, const void* z, const void* x, const float* bias,
+                                            const float* gamma, const float* mean, const float* rstd, void* dx,
+                                            void* dres, float* dgamma_partial, float* dbeta_partial,
+                                            float* dbias_partial, int n_partials, int dtype, int64_t rows, int cols,
+                                            int act, float p_drop, const uint64_t* seed_state, uint64_t stream_id,
+                                            void* stream) {
+    if (!dy || !z || !gamma || !mean || !rstd) return fail_arg("ln_bwd: null pointer");
+    if (act != SHG_ACT_NONE && !x) return fail_arg("ln_bwd: x is required when act != NONE");
+    if (int e = check_cols(dtype, cols, "ln_bwd: unsupported cols")) return e;
+    if (n_partials < 1 || n_partials > MAX_PARTIALS) return fail_arg("ln_bwd: bad n_partials");
+    if ((size_t)12 * cols * sizeof(float) > 160 * 1024) return fail_arg("ln_bwd: cols too large for LDS");
+    if (rows <= 0) return rows == 0 ? 0 : fail_arg("ln_bwd: negative rows");
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == SHG_F32
+               ? launch_ln_bwd<float>(dy, z, x, bias, gamma, mean, rstd, dx, dres, dgamma_partial, dbeta_partial, dbias_partial, n_partials, rows, cols, act, p_drop, seed_state, stream_id, st)
+               : launch_ln_bwd<bf16_t>(dy, z, x, bias, gamma, mean, rstd, dx, dres, dgamma_partial, dbeta_partial, dbias_partial, n_partials, rows, cols, act, p_drop, seed_state, stream_id, st);
+}
+
+extern "C" int shg_bias_act_fwd(const void* x, const float* bias, void* y, int dtype, int64_t rows, int cols, int act,
+                                float p_drop, const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+    if (!x || !y) return fail_arg("bias_act_fwd: null pointer");
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("bias_act_fwd: bad dtype");
+    const int V = dtype == SHG_BF16 ? 8 : 4;
+    if (cols <= 0 || cols % V) return fail_arg("bias_act_fwd: cols must be a multiple of the 16-byte vector");
+    if (act < 0 || act > 2 || p_drop < 0.f || p_drop >= 1.f) return fail_arg("bias_act_fwd: bad act/p_drop");
+    if (rows <= 0) return rows == 0 ? 0 : fail_arg("bias_act_fwd: negative rows");
+    const int64_t n_vec = rows * cols / V;
+    const uint32_t thr = dropout_threshold(p_drop);
+    const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    dim3 grid((unsigned)std::min<int64_t>((n_vec + 255) / 256, 2048)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define BA_FWD(T, ACT) hipLaunchKernelGGL((bias_act_fwd_kernel<T, ACT>), grid, block, 0, st, (const T*)x, bias, (T*)y, n_vec, cols, thr, scale, seed_state, stream_id)
+    if (dtype == SHG_F32) { if (act == 0) BA_FWD(float, 0); else if (act == 1) BA_FWD(float, 1); else BA_FWD(float, 2); }
+    else { if (act == 0) BA_FWD(bf16_t, 0); else if (act == 1) BA_FWD(bf16_t, 1); else BA_FWD(bf16_t, 2); }
+#undef BA_FWD
+    return check_launch("bias_act_fwd");
+}
+
+extern "C" int shg_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial,
+                                int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
+                                const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+    if (!x || !dy || !dx) return fail_arg("bias_act_bwd: null pointer");
+    if (int e = check_cols(dtype, cols, "bias_act_bwd: unsupported cols", 16)) return e;
+    if (n_partials < 1 || n_partials > MAX_PARTIALS) return fail_arg("bias_act_bwd: bad n_partials");
+    if (rows <= 0) return rows == 0 ? 0 : fail_arg("bias_act_bwd: negative rows");
+    const uint32_t thr = dropout_threshold(p_drop);
+    const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    dim3 grid(n_partials), block(256);
+    const size_t lds = (size_t)4 * cols * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (cols / (dtype == SHG_BF16 ? 8 : 4) + 63) / 64;
+#define BA_BWD2(T, ACT, NCH) hipLaunchKernelGGL((bias_act_bwd_kernel<T, ACT, NCH>), grid, block, lds, st, (const T*)x, bias, (const T*)dy, (T*)dx, dbias_partial, rows, cols, thr, scale, seed_state, stream_id)
+#define BA_BWD(T, ACT) do { if (nch <= 2) BA_BWD2(T, ACT, 2); else if (nch <= 4) BA_BWD2(T, ACT, 4); else if (nch <= 8) BA_BWD2(T, ACT, 8); else BA_BWD2(T, ACT, 16); } while (0)
+    if (dtype == SHG_F32) { if (act == 0) BA_BWD(float, 0); else if (act == 1) BA_BWD(float, 1); else BA_BWD(float, 2); }
+    else { if (act == 0) BA_BWD(bf16_t, 0); else if (act == 1) BA_BWD(bf16_t, 1); else BA_BWD(bf16_t, 2); }
+#undef BA_BWD
+#undef BA_BWD2
+    return check_launch("bias_act_bwd");
+}

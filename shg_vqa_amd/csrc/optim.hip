@@ -1,0 +1,153 @@
+// Optimiser on a flat fp32 parameter arena: global gradient norm, clip + BertAdam update with a
+// bf16 shadow copy written in the same pass.  Pure HBM streaming: 4 reads (p, g, m, v) and 3-4
+// writes (p, m, v, shadow) of 16 bytes per lane.
+#include <math.h>
+
+#include "common.h"
+
+namespace shg {
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    const int64_t n4 = n / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        acc += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += (double)x[i] * (double)x[i];
+    acc = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partial, int n_partial, float* __restrict__ out) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sqrt(sh[0]);
+}
+
+__device__ __forceinline__ double warmup_linear(double x, double warmup) {
+    if (x < warmup) return x / warmup;
+    const double y = (x - 1.0) / (warmup - 1.0);
+    return y > 0.0 ? y : 0.0;
+}
+
+__global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       bf16_t* __restrict__ shadow, int64_t n,
+                                                       const float* __restrict__ grad_norm, float max_norm, float lr,
+                                                       float warmup, int64_t t_total, float b1, float b2, float eps,
+                                                       float wd, const int64_t* __restrict__ step_state) {
+    float clip = 1.f;
+    if (grad_norm && max_norm > 0.f) clip = fminf(max_norm / (grad_norm[0] + 1e-6f), 1.f);
+    double lr_d = (double)lr;
+    if (t_total != -1) lr_d *= warmup_linear((double)step_state[0] / (double)t_total, (double)warmup);
+    const float lr_t = (float)lr_d;
+    const float one_b1 = 1.f - b1, one_b2 = 1.f - b2;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        bf16x4 sv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gg = gv[j] * clip;
+            mv[j] = mv[j] * b1 + one_b1 * gg;
+            vv[j] = vv[j] * b2 + one_b2 * gg * gg;
+            const float upd = mv[j] / (sqrtf(vv[j]) + eps) + wd * pv[j];
+            pv[j] -= lr_t * upd;
+            sv[j] = (bf16_t)pv[j];
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        if (shadow) reinterpret_cast<bf16x4*>(shadow)[i] = sv;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float gg = g[i] * clip;
+            const float mm = m[i] * b1 + one_b1 * gg, vv = v[i] * b2 + one_b2 * gg * gg;
+            m[i] = mm; v[i] = vv;
+            const float pp = p[i] - lr_t * (mm / (sqrtf(vv) + eps) + wd * p[i]);
+            p[i] = pp;
+            if (shadow) shadow[i] = (bf16_t)pp;
+        }
+}
+
+__global__ void add_i64_kernel(int64_t* p, int64_t d) { p[0] += d; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[i * 4 + j] = from_f32<T>(v[j]);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) dst[i] = from_f32<T>(src[i]);
+}
+
+}  // namespace shg
+
+using namespace shg;
+
+extern "C" int shg_sumsq(const float* x, int64_t n, double* partial, int n_partial, float* out_norm, void* stream) {
+    if (!x || !partial || !out_norm) return fail_arg("sumsq: null pointer");
+    if (n < 0 || n_partial < 1 || n_partial > 65535) return fail_arg("sumsq: bad sizes");
+    if (reinterpret_cast<uintptr_t>(x) & 15) return fail_arg("sumsq: x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(n_partial), dim3(256), 0, st, x, n, partial);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, partial, n_partial, out_norm);
+    return check_launch("sumsq");
+}
+
+extern "C" int shg_bertadam_arena(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+                                  const float* grad_norm, float max_norm, float lr, float warmup, int64_t t_total,
+                                  float b1, float b2, float eps, float weight_decay, int64_t* step_state, int bump_step,
+                                  void* stream) {
+    if (!param || !grad || !m || !v || !step_state) return fail_arg("bertadam: null pointer");
+    if (n < 0) return fail_arg("bertadam: negative n");
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15)
+        return fail_arg("bertadam: arenas must be 16-byte aligned");
+    if (shadow_bf16 && (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)) return fail_arg("bertadam: shadow must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (n > 0) {
+        const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, 4096);
+        hipLaunchKernelGGL(bertadam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, m, v, (bf16_t*)shadow_bf16,
+                           n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state);
+    }
+    if (bump_step) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, st, step_state, (int64_t)1);
+    return check_launch("bertadam_arena");
+}
+
+extern "C" int shg_add_i64(int64_t* p, int64_t delta, void* stream) {
+    if (!p) return fail_arg("add_i64: null pointer");
+    hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p, delta);
+    return check_launch("add_i64");
+}
+
+extern "C" int shg_cast_f32(const float* src, void* dst, int dtype, int64_t n, void* stream) {
+    if (!src || !dst) return fail_arg("cast: null pointer");
+    if (n < 0) return fail_arg("cast: negative n");
+    if (n == 0) return 0;
+    if (reinterpret_cast<uintptr_t>(src) & 15) return fail_arg("cast: src must be 16-byte aligned");
+    const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) hipLaunchKernelGGL(cast_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, src, (float*)dst, n);
+    else if (dtype == SHG_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    else return fail_arg("cast: bad dtype");
+    return check_launch("cast_f32");
+}

@@ -1,0 +1,389 @@
+"""Thin, shape-checked wrappers: torch tensors (device memory, current stream) -> C ABI calls.
+
+Each function validates shapes / dtypes / contiguity on the host BEFORE the launch (a kernel that
+faults can take the whole GPU host down) and then hands raw pointers to libshgvqa.so.
+torch is used for allocation and stream plumbing only.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, MASK_FULL, MASK_KEY, MASK_NONE  # noqa: F401
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("expected float32 or bfloat16 tensor, got %s" % t.dtype)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need(cond, msg):
+    if not cond:
+        raise ValueError(msg)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None:
+            _need(t.is_cuda, "tensor must live on the GPU (the HIP path has no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+def hungarian_per_frame(logits, tgt, tgt_len, background=0, want_grid=True):
+    """logits [N, R, C]; tgt [N, R] int64; tgt_len [N] int32 -> (query_idx, target_idx, grid) [N, R] int64."""
+    _dev(logits, tgt, tgt_len)
+    _need(logits.dim() == 3 and logits.is_contiguous(), "logits must be contiguous [N, R, C]")
+    n, r, c = logits.shape
+    _need(1 <= r <= 8, "per_frame must be in [1, 8]")
+    _need(tgt.shape == (n, r) and tgt.dtype == torch.int64 and tgt.is_contiguous(), "tgt must be int64 [N, R]")
+    _need(tgt_len.shape == (n,) and tgt_len.dtype == torch.int32 and tgt_len.is_contiguous(), "tgt_len must be int32 [N]")
+    oq = torch.empty((n, r), dtype=torch.int64, device=logits.device)
+    ot = torch.empty_like(oq)
+    grid = torch.empty_like(oq) if want_grid else None
+    _lib.call("shg_hungarian_per_frame", logits.data_ptr(), _dt(logits), n, r, c, tgt.data_ptr(), tgt_len.data_ptr(),
+              int(background), oq.data_ptr(), ot.data_ptr(), _p(grid), _stream())
+    return oq, ot, grid
+
+
+def lsap_batched(cost, n_cols):
+    """cost [N, R, Cmax] fp32; n_cols [N] int32 -> (rows, cols) [N, Cmax] int64, -1 padded."""
+    _dev(cost, n_cols)
+    _need(cost.dim() == 3 and cost.dtype == torch.float32 and cost.is_contiguous(), "cost must be fp32 [N,R,C]")
+    n, r, cm = cost.shape
+    _need(1 <= cm <= r <= 8, "need 1 <= Cmax <= R <= 8")
+    _need(n_cols.shape == (n,) and n_cols.dtype == torch.int32, "n_cols must be int32 [N]")
+    orow = torch.empty((n, cm), dtype=torch.int64, device=cost.device)
+    ocol = torch.empty_like(orow)
+    _lib.call("shg_lsap_batched", cost.data_ptr(), n, r, cm, n_cols.data_ptr(), orow.data_ptr(), ocol.data_ptr(), _stream())
+    return orow, ocol
+
+
+# ------------------------------------------------------------------------------------------------
+def weighted_ce_fwd(logits, target, class_weight, background=0):
+    """logits [rows, C] contiguous; target [rows] int64 -> (row_stats [4, rows], sums [4])."""
+    _dev(logits, target, class_weight)
+    _need(logits.dim() == 2 and logits.is_contiguous(), "logits must be contiguous [rows, C]")
+    rows, c = logits.shape
+    _need(target.shape == (rows,) and target.dtype == torch.int64 and target.is_contiguous(), "target int64 [rows]")
+    _need(class_weight.shape == (c,) and class_weight.dtype == torch.float32, "class_weight fp32 [C]")
+    stats = torch.empty((4, rows), dtype=torch.float32, device=logits.device)
+    sums = torch.empty(4, dtype=torch.float32, device=logits.device)
+    _lib.call("shg_weighted_ce_fwd", logits.data_ptr(), _dt(logits), rows, c, target.data_ptr(), class_weight.data_ptr(),
+              int(background), stats.data_ptr(), sums.data_ptr(), _stream())
+    return stats, sums
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def weighted_ce_bwd(logits, target, class_weight, stats, sums, gscale=None, padded=False):
+    """-> dlogits [rows, C] (or [rows, pad8(C)] with zeroed pad columns when padded)."""
+    _dev(logits, target, class_weight, stats, sums, gscale)
+    rows, c = logits.shape
+    _need(stats.shape == (4, rows) and sums.numel() >= 2, "stats/sums from weighted_ce_fwd required")
+    ldd = pad8(c) if padded else c
+    d = torch.empty((rows, ldd), dtype=logits.dtype, device=logits.device)
+    _lib.call("shg_weighted_ce_bwd", logits.data_ptr(), _dt(logits), rows, c, target.data_ptr(), class_weight.data_ptr(),
+              stats.data_ptr(), sums.data_ptr(), _p(gscale), d.data_ptr(), ldd, _stream())
+    return d
+
+
+def bce_logits(logits, target, gscale=None, want_grad=True, padded=False):
+    """-> (loss [1] = C * mean BCE, dlogits or None; [rows, pad8(C)] when padded)."""
+    _dev(logits, target, gscale)
+    _need(logits.dim() == 2 and logits.is_contiguous(), "logits must be contiguous [rows, C]")
+    _need(target.shape == logits.shape and target.dtype == torch.float32 and target.is_contiguous(), "target fp32 [rows, C]")
+    rows, c = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    ldd = pad8(c) if padded else c
+    d = torch.empty((rows, ldd), dtype=logits.dtype, device=logits.device) if want_grad else None
+    _lib.call("shg_bce_logits_fwd_bwd", logits.data_ptr(), _dt(logits), rows, c, target.data_ptr(), _p(gscale),
+              loss.data_ptr(), _p(d), ldd, _stream())
+    return loss, d
+
+
+# ------------------------------------------------------------------------------------------------
+def _rows_cols(x):
+    _need(x.is_contiguous() and x.dim() >= 2, "activation must be contiguous with >= 2 dims")
+    return x.numel() // x.shape[-1], x.shape[-1]
+
+
+def _f32vec(t, n, name):
+    if t is not None:
+        _need(t.dtype == torch.float32 and t.numel() == n and t.is_contiguous(), "%s must be contiguous fp32 [%d]" % (name, n))
+
+
+def colsum_partials(rows):
+    return _lib.lib().shg_colsum_partials(int(rows))
+
+
+def colsum(x2d, out, accumulate):
+    """out[c] (+)= sum_r x2d[r, c]; x2d may be a row-strided view."""
+    _dev(x2d, out)
+    _need(x2d.dim() == 2 and x2d.stride(1) == 1, "x must be 2-D with contiguous inner dim")
+    rows, cols = x2d.shape
+    npart = colsum_partials(rows)
+    part = torch.empty((npart, cols), dtype=torch.float32, device=x2d.device)
+    _lib.call("shg_colsum_partial", x2d.data_ptr(), _dt(x2d), rows, cols, x2d.stride(0), part.data_ptr(), npart, _stream())
+    colsum_finish(part, out, accumulate)
+
+
+def colsum_finish(partial, out, accumulate):
+    n_partials, cols = partial.shape
+    _need(out.numel() == cols and out.dtype == torch.float32 and out.is_contiguous(), "out must be fp32 [cols]")
+    _lib.call("shg_colsum_finish", partial.data_ptr(), n_partials, cols, out.data_ptr(), 1 if accumulate else 0, _stream())
+
+
+def bias_act_fwd(x, bias, act, p_drop=0.0, seed_state=None, stream_id=0):
+    _dev(x, bias, seed_state)
+    rows, cols = _rows_cols(x)
+    _f32vec(bias, cols, "bias")
+    _need(p_drop == 0.0 or seed_state is not None, "dropout needs seed_state")
+    y = torch.empty_like(x)
+    _lib.call("shg_bias_act_fwd", x.data_ptr(), _p(bias), y.data_ptr(), _dt(x), rows, cols, act, float(p_drop),
+              _p(seed_state), int(stream_id), _stream())
+    return y
+
+
+def bias_act_bwd(x, bias, dy, act, p_drop=0.0, seed_state=None, stream_id=0, want_dbias=True):
+    """-> (dx, dbias_partial [n_partials, cols] or None)."""
+    _dev(x, bias, dy, seed_state)
+    rows, cols = _rows_cols(x)
+    _need(dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous(), "dy must match x")
+    dx = torch.empty_like(x)
+    npart = colsum_partials(rows)
+    part = torch.empty((npart, cols), dtype=torch.float32, device=x.device) if want_dbias else None
+    _lib.call("shg_bias_act_bwd", x.data_ptr(), _p(bias), dy.data_ptr(), dx.data_ptr(), _p(part), npart, _dt(x), rows,
+              cols, act, float(p_drop), _p(seed_state), int(stream_id), _stream())
+    return dx, part
+
+
+def ln_fwd(x, bias, residual, gamma, beta, eps, act=ACT_NONE, p_drop=0.0, seed_state=None, stream_id=0, save_z=True):
+    """y = LN(dropout(act(x + bias)) + residual).  -> (y, z or None, mean, rstd)."""
+    _dev(x, bias, residual, gamma, beta, seed_state)
+    rows, cols = _rows_cols(x)
+    _f32vec(bias, cols, "bias")
+    _f32vec(gamma, cols, "gamma")
+    _f32vec(beta, cols, "beta")
+    if residual is not None:
+        _need(residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous(), "residual must match x")
+    _need(p_drop == 0.0 or seed_state is not None, "dropout needs seed_state")
+    y = torch.empty_like(x)
+    z = torch.empty_like(x) if save_z else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.call("shg_bias_act_drop_res_ln_fwd", x.data_ptr(), _p(bias), _p(residual), gamma.data_ptr(), beta.data_ptr(),
+              y.data_ptr(), _p(z), mean.data_ptr(), rstd.data_ptr(), _dt(x), rows, cols, act, float(eps), float(p_drop),
+              _p(seed_state), int(stream_id), _stream())
+    return y, z, mean, rstd
+
+
+def ln_bwd(dy, z, x, bias, gamma, mean, rstd, act=ACT_NONE, p_drop=0.0, seed_state=None, stream_id=0,
+           want_dx=True, want_dres=True, want_dbias=True):
+    """-> (dx, dres, dgamma_partial, dbeta_partial, dbias_partial)."""
+    _dev(dy, z, x, bias, gamma, mean, rstd, seed_state)
+    rows, cols = _rows_cols(dy)
+    _need(z.shape == dy.shape and z.dtype == dy.dtype and z.is_contiguous(), "z must match dy")
+    if act != ACT_NONE:
+        _need(x is not None and x.shape == dy.shape and x.dtype == dy.dtype, "x required when act != NONE")
+    _need(mean.numel() == rows and rstd.numel() == rows, "mean/rstd must have one entry per row")
+    npart = colsum_partials(rows)
+    dx = torch.empty_like(dy) if want_dx else None
+    dres = torch.empty_like(dy) if want_dres else None
+    dg = torch.empty((npart, cols), dtype=torch.float32, device=dy.device)
+    db = torch.empty_like(dg)
+    dbi = torch.empty_like(dg) if want_dbias else None
+    _lib.call("shg_bias_act_drop_res_ln_bwd", dy.data_ptr(), z.data_ptr(), _p(x), _p(bias), gamma.data_ptr(),
+              mean.data_ptr(), rstd.data_ptr(), _p(dx), _p(dres), dg.data_ptr(), db.data_ptr(), _p(dbi), npart, _dt(dy),
+              rows, cols, act, float(p_drop), _p(seed_state), int(stream_id), _stream())
+    return dx, dres, dg, db, dbi
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_view(t, name):
+    """t: [B, S, H*64]-like view with unit stride over the last dim.  -> (B, S, bstride, sstride)."""
+    _need(t.dim() == 3 and t.stride(2) == 1, "%s must be [B, S, H*64] with a contiguous last dim" % name)
+    return t.shape[0], t.shape[1], t.stride(0), t.stride(1)
+
+
+def _mask_args(mask_kind, mask, b, sq, sk):
+    if mask_kind == MASK_NONE:
+        return None
+    _need(mask is not None and mask.dtype == torch.float32 and mask.is_contiguous(), "mask must be contiguous fp32")
+    if mask_kind == MASK_KEY:
+        _need(mask.numel() == b * sk, "key mask must have B*Sk elements")
+    else:
+        _need(mask.numel() == sq * sk, "full mask must have Sq*Sk elements")
+    return mask
+
+
+def attention_fwd(q, k, v, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p_drop=0.0, seed_state=None, stream_id=0):
+    """q [B,Sq,H*64], k/v [B,Sk,H*64] (views into fused projections allowed) -> (o [B,Sq,H*64], lse [B,H,Sq])."""
+    _dev(q, k, v, mask, seed_state)
+    b, sq, qb, qs = _attn_view(q, "q")
+    b2, sk, kb, ks = _attn_view(k, "k")
+    b3, sk2, vb, vs = _attn_view(v, "v")
+    _need(b == b2 == b3 and sk == sk2, "batch / key length mismatch")
+    _need(q.shape[2] == heads * 64 and k.shape[2] == heads * 64 and v.shape[2] == heads * 64, "head dim must be 64")
+    _need(q.dtype == k.dtype == v.dtype, "q/k/v dtype mismatch")
+    mask = _mask_args(mask_kind, mask, b, sq, sk)
+    _need(p_drop == 0.0 or seed_state is not None, "dropout needs seed_state")
+    o = torch.empty((b, sq, heads * 64), dtype=q.dtype, device=q.device)
+    lse = torch.empty((b, heads, sq), dtype=torch.float32, device=q.device)
+    _lib.call("shg_attention_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), _dt(q), b,
+              heads, sq, sk, qb, qs, kb, ks, vb, vs, mask_kind, _p(mask), float(scale), float(p_drop), _p(seed_state),
+              int(stream_id), _stream())
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, d_o, lse, dq, dk, dv, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p_drop=0.0,
+                  seed_state=None, stream_id=0):
+    """Writes dq/dk/dv (views with the same layout rules as q/k/v)."""
+    _dev(q, k, v, o, d_o, lse, dq, dk, dv, mask, seed_state)
+    b, sq, qb, qs = _attn_view(q, "q")
+    _, sk, kb, ks = _attn_view(k, "k")
+    _, _, vb, vs = _attn_view(v, "v")
+    _need(o.is_contiguous() and d_o.is_contiguous() and o.shape == (b, sq, heads * 64) and d_o.shape == o.shape,
+          "o and d_o must be contiguous [B,Sq,H*64]")
+    _need(o.dtype == q.dtype and d_o.dtype == q.dtype, "o/d_o dtype mismatch")
+    _need(lse.shape == (b, heads, sq) and lse.dtype == torch.float32 and lse.is_contiguous(), "lse [B,H,Sq] fp32")
+    _, sq2, dqb, dqs = _attn_view(dq, "dq")
+    _, sk2, dkb, dks = _attn_view(dk, "dk")
+    _, sk3, dvb, dvs = _attn_view(dv, "dv")
+    _need(sq2 == sq and sk2 == sk and sk3 == sk and dq.dtype == q.dtype and dk.dtype == q.dtype and dv.dtype == q.dtype,
+          "gradient buffers must match q/k/v")
+    mask = _mask_args(mask_kind, mask, b, sq, sk)
+    delta = torch.empty((b, heads, sq), dtype=torch.float32, device=q.device)
+    _lib.call("shg_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+              delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _dt(q), b, heads, sq, sk, qb, qs, kb, ks,
+              vb, vs, dqb, dqs, dkb, dks, dvb, dvs, mask_kind, _p(mask), float(scale), float(p_drop), _p(seed_state),
+              int(stream_id), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(a, b, out, bias=None, a_kmajor=True, b_kmajor=True, accumulate=False):
+    """out[M,N] (+)= A . B (+ bias).  a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N].
+    2-D tensors with unit inner stride (row stride = leading dimension)."""
+    _dev(a, b, out, bias)
+    for t, nm in ((a, "a"), (b, "b"), (out, "out")):
+        _need(t.dim() == 2 and t.stride(1) == 1, "%s must be 2-D with a contiguous inner dimension" % nm)
+    _need(a.dtype == b.dtype, "a/b dtype mismatch")
+    m, k = (a.shape if a_kmajor else (a.shape[1], a.shape[0]))
+    n, k2 = (b.shape if b_kmajor else (b.shape[1], b.shape[0]))
+    _need(k == k2 or (a_kmajor and b_kmajor is False and False), "contraction size mismatch: %d vs %d" % (k, k2))
+    _need(out.shape == (m, n), "out must be [%d, %d]" % (m, n))
+    _f32vec(bias, n, "bias")
+    _lib.call("shg_gemm", a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _dt(a), _dt(out), m, n, k, a.stride(0),
+              b.stride(0), out.stride(0), 1 if a_kmajor else 0, 1 if b_kmajor else 0, 1 if accumulate else 0, _stream())
+    return out
+
+
+_conv_ws = {}
+
+
+def conv_workspace(B, T, H, W, device):
+    """Gather tables of the (5,3,3) conv for one input shape (built once, cached)."""
+    key = (B, T, H, W, str(device))
+    ws = _conv_ws.get(key)
+    if ws is None:
+        nbytes = _lib.lib().shg_conv3d_k533_workspace_bytes(B, T, H, W)
+        _need(nbytes > 0, "bad conv shape")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.call("shg_conv3d_k533_prepare", ws.data_ptr(), B, T, H, W, _stream())
+        _conv_ws[key] = ws
+    return ws
+
+
+def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, out_dtype=None):
+    """x_cl [B,T,H+2,W+2,Cin] (zero border); w_cl [Cout,5,3,3,Cin]; -> y [B,T-4,H,W,Cout]
+    (or written into the interior of a zero-bordered [B,T-4,H+2,W+2,Cout] buffer when pad_out)."""
+    _dev(x_cl, w_cl, bias, out)
+    _need(x_cl.dim() == 5 and x_cl.is_contiguous() and w_cl.dim() == 5 and w_cl.is_contiguous(), "channels-last 5-D tensors")
+    B, T, Hp, Wp, cin = x_cl.shape
+    H, W = Hp - 2, Wp - 2
+    cout = w_cl.shape[0]
+    _need(tuple(w_cl.shape) == (cout, 5, 3, 3, cin) and w_cl.dtype == x_cl.dtype, "weight must be [Cout,5,3,3,Cin] of x's dtype")
+    _f32vec(bias, cout, "bias")
+    ws = conv_workspace(B, T, H, W, x_cl.device)
+    if out is None:
+        shape = (B, T - 4, Hp, Wp, cout) if pad_out else (B, T - 4, H, W, cout)
+        out = (torch.zeros if pad_out else torch.empty)(shape, dtype=x_cl.dtype, device=x_cl.device)
+    _need(out.is_contiguous() and out.dtype == x_cl.dtype, "out must be contiguous and of x's dtype")
+    _lib.call("shg_conv3d_k533_fwd", x_cl.data_ptr(), w_cl.data_ptr(), _p(bias), out.data_ptr(), _dt(x_cl), B, T, H, W, cin,
+              cout, act, 1 if pad_out else 0, ws.data_ptr(), _stream())
+    return out
+
+
+def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False):
+    """dw [Cout,5,3,3,Cin] fp32 (+)= sum over positions of dy [B,T-4,H,W,Cout] x gathered x_cl."""
+    _dev(x_cl, dy, dw)
+    B, T, Hp, Wp, cin = x_cl.shape
+    H, W = Hp - 2, Wp - 2
+    cout = dy.shape[-1]
+    _need(x_cl.is_contiguous() and dy.is_contiguous() and tuple(dy.shape) == (B, T - 4, H, W, cout) and dy.dtype == x_cl.dtype,
+          "dy must be contiguous [B,T-4,H,W,Cout] of x's dtype")
+    _need(tuple(dw.shape) == (cout, 5, 3, 3, cin) and dw.dtype == torch.float32 and dw.is_contiguous(), "dw fp32 [Cout,5,3,3,Cin]")
+    ws = conv_workspace(B, T, H, W, x_cl.device)
+    _lib.call("shg_conv3d_k533_wgrad", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
+              1 if accumulate else 0, ws.data_ptr(), _stream())
+    return dw
+
+
+def ncdhw_to_padded_cl(x, dtype):
+    """[B,C,T,H,W] fp32 -> [B,T,H+2,W+2,C] `dtype`, zero border."""
+    _dev(x)
+    _need(x.dim() == 5 and x.dtype == torch.float32 and x.is_contiguous(), "x must be contiguous fp32 NCDHW")
+    B, C, T, H, W = x.shape
+    y = torch.zeros((B, T, H + 2, W + 2, C), dtype=dtype, device=x.device)
+    _lib.call("shg_ncdhw_to_padded_cl", x.data_ptr(), y.data_ptr(), _dt(y), B, C, T, H, W, _stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+def grad_norm(flat_grad, partial=None):
+    """L2 norm of a flat fp32 arena -> fp32 [1] (device)."""
+    _dev(flat_grad)
+    _need(flat_grad.dtype == torch.float32 and flat_grad.is_contiguous() and flat_grad.dim() == 1, "flat fp32 arena")
+    npart = 1024
+    if partial is None:
+        partial = torch.empty(npart, dtype=torch.float64, device=flat_grad.device)
+    out = torch.empty(1, dtype=torch.float32, device=flat_grad.device)
+    _lib.call("shg_sumsq", flat_grad.data_ptr(), flat_grad.numel(), partial.data_ptr(), npart, out.data_ptr(), _stream())
+    return out
+
+
+def bertadam_arena(param, grad, m, v, shadow, grad_norm_t, max_norm, lr, warmup, t_total, step_state, b1=0.9, b2=0.999,
+                   eps=1e-6, weight_decay=0.01, bump_step=True):
+    _dev(param, grad, m, v, shadow, grad_norm_t, step_state)
+    n = param.numel()
+    for t, nm in ((param, "param"), (grad, "grad"), (m, "m"), (v, "v")):
+        _need(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n, "%s must be a flat fp32 arena" % nm)
+    if shadow is not None:
+        _need(shadow.dtype == torch.bfloat16 and shadow.numel() == n and shadow.is_contiguous(), "shadow bf16 arena")
+    _need(step_state.dtype == torch.int64 and step_state.numel() >= 1, "step_state int64")
+    _lib.call("shg_bertadam_arena", param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _p(shadow), n,
+              _p(grad_norm_t), float(max_norm), float(lr), float(warmup), int(t_total), float(b1), float(b2), float(eps),
+              float(weight_decay), step_state.data_ptr(), 1 if bump_step else 0, _stream())
+
+
+def add_i64(t, delta):
+    _dev(t)
+    _need(t.dtype == torch.int64 or t.dtype == torch.uint64, "int64 counter")
+    _lib.call("shg_add_i64", t.data_ptr(), int(delta), _stream())
+
+
+def cast_f32(src, dst):
+    _dev(src, dst)
+    _need(src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == src.numel(),
+          "cast: contiguous fp32 source and same-size destination")
+    _lib.call("shg_cast_f32", src.data_ptr(), dst.data_ptr(), _dt(dst), src.numel(), _stream())
