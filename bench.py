@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the SHG-VQA hot path on MI355X: full --taskHGQA training steps (5/2/5 layers, 5 decoder
+layers, B=32 x 16 frames x 2048-d slow_r50-shaped features, --LossHGPerFrame, bf16 operands / fp32
+accumulation and fp32 master weights) on synthetic AGQA-shaped batches that are resident in HBM when
+the timed region starts.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
+
+One step = forward -> BCE + Hungarian set losses -> backward -> global-norm clip -> BertAdam (nothing
+skipped).  Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel (the implicit-GEMM
+(5,3,3) Conv3d 2048->768: 46 % of the step's algorithmic FLOPs) timed with events on its own stream
+inside the timed steps; `cpu_baseline` is the CPU oracle (oracle/shg_ref.py) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+TRAIN_GFLOP_PER_QA = 428.21        # fwd + required bwd GEMM-like work per QA pair (HGQA)
+
+
+def synthetic_device_batches(n_batches, bsz, seed, device):
+    from shg_vqa_amd.agqa_hgqa import SyntheticAGQA, batch_to_device
+    ds = SyntheticAGQA(n=n_batches * bsz, seed=seed, feat_pool=min(16, n_batches * bsz))
+    out = []
+    for i in range(n_batches):
+        items = [ds[i * bsz + j] for j in range(bsz)]
+        batch = {k: (torch.stack([it[k] for it in items]) if torch.is_tensor(items[0][k]) else torch.tensor([it[k] for it in items]))
+                 for k in items[0]}
+        out.append(batch_to_device(batch, device))
+    return out
+
+
+def cpu_baseline(bsz=4, timed=2):
+    """The CPU oracle's full train step (same arithmetic, fp32, dropout on) on this box's host cores."""
+    from oracle import shg_ref
+    # the box's CPU share, not the host's core count (oversubscribing the cgroup makes MKL crawl)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))
+    cfg = shg_ref.Cfg()
+    p = shg_ref.det_params(cfg, requires_grad=True)
+    state = {}
+    times = []
+    for step in range(1 + timed):
+        batch = shg_ref.synthetic_batch(bsz, cfg, seed=1234 + step)
+        t0 = time.perf_counter()
+        shg_ref.train_step(p, cfg, batch, state, lr=1e-5, step=step, t_total=1000, train=True)
+        times.append(time.perf_counter() - t0)
+        log("  oracle step %d: %.1f s" % (step, times[-1]))
+    per = sum(times[1:]) / timed
+    return {"value": round(bsz / per, 4), "unit": "QA-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/shg_ref.train_step, B=%d slice of the B=32 workload, fp32, dropout on, 1 warm-up + %d timed steps "
+                      "(%.1f s/step)" % (bsz, timed, per)}
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from shg_vqa_amd.agqa_hgqa import AGQA, DataTuple, SyntheticAGQA
+    from shg_vqa_amd.agqa_model import AGQAModel
+    from shg_vqa_amd.ddp import GradReducer
+    from shg_vqa_amd.engine import engine, reset_engine
+    from shg_vqa_amd.param import hgqa_args
+
+    log("imports done; building model")
+    cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    reset_engine(compute_dtype=cdt, device=dev, seed=9595 + rank)
+    args = hgqa_args(compute_dtype=a.dtype, batch_size=a.batch, lr=1e-5)
+    torch.manual_seed(9595)                                   # identical --fromScratch initialisation on every rank
+    model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=args)
+    model.to_engine(cdt)
+    E = engine()
+    reducer = GradReducer(E.grad_arena) if world > 1 else None
+    trainer = AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=1), [None] * 1000, None), model=model, t_total=10000,
+                   world=reducer)
+    log("model in HBM arenas (%d params, %d with gradients); building batches" % (E.n_total, E.n_active))
+    batches = synthetic_device_batches(4, a.batch, 1234 + rank, dev)
+    log("batches resident; warm-up")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        trainer.train_step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
+    sync()
+    E.kernel_events = []
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        trainer.train_step(batches[i % len(batches)])
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    log("timed region: %.3f s for %d steps" % (elapsed, a.steps))
+
+    # dominant kernel: conv1 implicit GEMM, events recorded around its launch on its own stream
+    evs = E.kernel_events or []
+    E.kernel_events = None
+    k_ms = sum(s.elapsed_time(e) for s, e in evs) / max(len(evs), 1)
+    B = a.batch
+    conv1_flop = 2.0 * (B * 12 * 49) * 768 * (45 * 2048)
+    achieved = conv1_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+
+    if rank == 0:
+        qa = world * B * a.steps / elapsed
+        line = {
+            "metric": "training QA-pairs/sec (node) for 5/2/5-layer SHG-VQA", "value": round(qa, 2), "unit": "QA-pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "agqaHGQA.py --taskHGQA --LossHGPerFrame full SHG-VQA model, llayers/xlayers/rlayers 5/2/5, "
+                                   "dlayers 5, slow_r50-shaped feats (B,2048,16,7,7), per-GPU batch %d, random --fromScratch init "
+                                   "(BASELINE.json configs[2]; configs[4] at 8 GPUs)" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "step_mfma_frac": round(qa / world * TRAIN_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": {"kernel": "gemm_kernel<bf16, ConvRowSrc> (shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(k_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (oracle) ...")
+            line["cpu_baseline"] = cpu_baseline()
+            log("cpu baseline done")
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

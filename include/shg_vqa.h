@@ -180,7 +180,8 @@ int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype
  *   x  [B, T, H+2, W+2, Cin]   (dtype) channels-last, spatially pre-padded with zeros
  *   w  [Cout, 5, 3, 3, Cin]    (dtype) = the reference weight [Cout,Cin,5,3,3] permuted
  *   y  [B, T-4, H, W, Cout]    (dtype_y), y = act(conv + bias); if pad_out != 0 y is written into a
- *      spatially padded [B, T-4, H+2, W+2, Cout] buffer (border untouched, must be pre-zeroed)
+ *      spatially padded [B, T-4, H+2, W+2, Cout] buffer (border untouched, must be pre-zeroed);
+ *      y_pre (optional) [B, T-4, H, W, Cout] receives conv + bias before the activation (needed by backward)
  *   wgrad: dw [Cout,5,3,3,Cin] fp32 (+= when accumulate), dy [B,T-4,H,W,Cout] (dtype)
  *   The input gradient is the same forward kernel applied to dy zero-padded by 4 in T and 1 in H/W
  *   with the weight flipped and transposed ([Cin][4-kt][2-kh][2-kw][Cout]); the host does that
@@ -191,7 +192,8 @@ int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype
 int64_t shg_conv3d_k533_workspace_bytes(int B, int T, int H, int W);
 int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int W, void* stream);
 int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T, int H,
-                        int W, int Cin, int Cout, int act, int pad_out, const void* workspace, void* stream);
+                        int W, int Cin, int Cout, int act, int pad_out, void* y_pre, const void* workspace,
+                        void* stream);
 int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                           int Cin, int Cout, int accumulate, const void* workspace, void* stream);
 /* NCDHW fp32 features -> channels-last, spatially zero-padded (dtype) : [B,C,T,H,W] -> [B,T,H+2,W+2,C] */

@@ -1,0 +1,245 @@
+"""Training-loop entry points of AGQA/src/tasks/agqaHGQA.py on the HIP path: get_tuple(), class AGQA
+with train() / predict() / evaluate() / save() / load(), and the single-step function the benchmark
+times.  One optimiser step = host batch hand-over -> forward -> BCE + Hungarian set losses ->
+backward -> global-norm clip -> BertAdam, with no device->host synchronisation inside the step.
+
+The AGQA dataset, tokenizer vocabulary and frozen video backbone are not part of the hot path (and
+not available offline); get_tuple() therefore serves synthetic AGQA-shaped batches with the batch
+tuple layout of agqa_data.py:266.
+"""
+import collections
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .agqa_model import AGQAModel
+from .engine import engine
+from .entry import frame_segment_ids
+from .matcher import HungarianMatcher
+from .optimization import BertAdam, clip_grad_norm_
+
+DataTuple = collections.namedtuple("DataTuple", "dataset loader evaluator")
+
+
+class SyntheticAGQA(torch.utils.data.Dataset):
+    """AGQA-shaped synthetic samples: slow_r50-shaped features, a tokenised question,
+    per-frame relation / action targets with distinct classes, a one-hot answer."""
+
+    num_answers = 171
+    action_classes = list(range(157))
+    num_situations, num_rel, num_act = 16, 8, 3
+    rel_classes = 456
+
+    def __init__(self, n=256, seed=1234, feat_pool=8):
+        self.n, self.seed = n, seed
+        g = torch.Generator().manual_seed(seed)
+        self.feat_pool = [torch.randn(2048, 16, 7, 7, generator=g) for _ in range(feat_pool)]
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 7919 + i)
+        t = self.num_situations
+        n = int(torch.randint(8, 31, (1,), generator=g))
+        ids = torch.zeros(40, dtype=torch.int64)
+        ids[:n] = torch.randint(1000, 30522, (n,), generator=g)
+        ids[0], ids[n - 1] = 101, 102
+        mask = torch.zeros(40, dtype=torch.int64)
+        mask[:n] = 1
+
+        def ragged(per, ncls):
+            tri = torch.zeros(t, per, dtype=torch.int64)
+            lens = torch.randint(0, per + 1, (t,), generator=g)
+            for f in range(t):
+                k = int(lens[f])
+                tri[f, :k] = torch.randperm(ncls, generator=g)[:k] + 1
+            return tri, lens
+
+        rel, rel_len = ragged(self.num_rel, self.rel_classes)
+        act, act_len = ragged(self.num_act, len(self.action_classes))
+        target = torch.zeros(self.num_answers)
+        target[int(torch.randint(0, self.num_answers, (1,), generator=g))] = 1.0
+        return dict(ques_id=i, feat=self.feat_pool[i % len(self.feat_pool)], pos=torch.ones(393),
+                    input_ids=ids, input_mask=mask, segment_ids=torch.zeros(40, dtype=torch.int64),
+                    rel_triplets=rel, lengths=rel_len, act_tokens=act, act_lengths=act_len,
+                    hg_mask=torch.cat([(act > 0), (rel > 0)], dim=1).float(), target=target)
+
+
+class Evaluator:
+    """Top-1 answer accuracy (the per-category tables of AGQAEvaluator, agqa_data.py:341-1101, need the
+    real annotations and are out of scope)."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def evaluateOverall(self, quesid2ans):
+        if not quesid2ans:
+            return 0.0
+        hit = sum(int(self.dataset[q]["target"].argmax()) == int(a) for q, a in quesid2ans.items())
+        return hit / len(quesid2ans)
+
+
+def get_tuple(splits, bs, shuffle=False, drop_last=False, n=256, seed=1234):
+    """agqaHGQA.py:50-63."""
+    dset = SyntheticAGQA(n=n, seed=seed + (0 if "train" in splits else 1))
+    loader = torch.utils.data.DataLoader(dset, batch_size=bs, shuffle=shuffle, drop_last=drop_last, num_workers=0)
+    return DataTuple(dataset=dset, loader=loader, evaluator=Evaluator(dset))
+
+
+def batch_to_device(batch, device):
+    """ONE host->device hand-over per tensor; the ragged per-frame targets travel as the padded
+    (B,16,per) + lengths arrays the dataset already holds (the reference makes 2*B*16 tiny copies,
+    agqaHGQA.py:304-318)."""
+    out = {}
+    for k, v in batch.items():
+        out[k] = v.to(device, non_blocking=True) if torch.is_tensor(v) else v
+    out["lengths"] = out["lengths"].to(torch.int32)
+    out["act_lengths"] = out["act_lengths"].to(torch.int32)
+    return out
+
+
+class AGQA:
+    def __init__(self, args=None, train_tuple=None, valid_tuple=None, model=None, t_total=None, world=None):
+        if args is None:
+            from .param import hgqa_args
+            args = hgqa_args()
+        self.args = args
+        self.device = torch.device("cuda")
+        self.train_tuple = train_tuple if train_tuple is not None else get_tuple(args.train, args.batch_size, True, True)
+        self.valid_tuple = valid_tuple
+        dset = self.train_tuple.dataset
+        self.num_situations, self.num_rel, self.num_act = dset.num_situations, dset.num_rel, dset.num_act
+        self.num_actions = len(dset.action_classes)
+        self.rel_classes = getattr(dset, "rel_classes", 456)
+        self.clip_len = args.CLIP_LEN
+        self.background_idx = 0
+        E = engine()
+        E.compute_dtype = torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32
+        self.model = model if model is not None else AGQAModel(dset.num_answers, num_queries=self.num_rel * self.num_situations,
+                                                                num_classes=self.rel_classes, num_actions=self.num_actions,
+                                                                args=args)
+        if E.model is not self.model:
+            self.model.to_engine()
+        self.empty_weight = torch.ones(self.rel_classes + 1, device=self.device)
+        self.empty_weight[self.background_idx] = 0.1
+        self.empty_weight_acts = torch.ones(self.num_actions + 1, device=self.device)
+        self.empty_weight_acts[self.background_idx] = 0.1
+        self.matcher = HungarianMatcher(cost_class=1, loss_hg_per_frame=args.loss_hg_per_frame, clip_len=self.clip_len)
+        if t_total is None:
+            t_total = int(len(self.train_tuple.loader) * args.epochs)
+        self.optim = BertAdam(list(self.model.parameters()), lr=args.lr, warmup=0.1, t_total=t_total)
+        self.output = args.output
+        self.world = world            # shg_vqa_amd.ddp.GradReducer or None
+        if world is not None:
+            E.grad_ready_hook = world.on_grad
+
+    # ------------------------------------------------------------------ one step
+    def forward_losses(self, b):
+        """Forward + losses of agqaHGQA.py:326-378 on a device batch.  Returns a dict of device scalars."""
+        a = self.args
+        B = b["input_ids"].shape[0]
+        dev = b["input_ids"].device
+        if a.task_hgqa:
+            rel_seg = frame_segment_ids(B, self.num_situations, self.num_rel, dev)
+            act_seg = frame_segment_ids(B, self.num_situations, self.num_act, dev)
+            logit, rel_logit, act_logit, hg_logit, _ = self.model(
+                b["feat"], b["pos"], input_ids=b["input_ids"], input_masks=b["input_mask"], segment_ids=b["segment_ids"],
+                rel_segment_ids=rel_seg, act_segment_ids=act_seg, hg_mask=b.get("hg_mask"))
+            bce = ops.bce_with_logits_times_c(hg_logit, b["target"])
+            rs, rgrid, rq, rt = ops.set_loss(rel_logit, b["rel_triplets"].view(-1, self.num_rel), b["lengths"].view(-1),
+                                             self.empty_weight, self.num_rel)
+            as_, agrid, aq, at = ops.set_loss(act_logit, b["act_tokens"].view(-1, self.num_act), b["act_lengths"].view(-1),
+                                              self.empty_weight_acts, self.num_act)
+            if self.world is not None:
+                rs, as_ = self.world.global_loss_sums(rs), self.world.global_loss_sums(as_)
+            rel_ce, act_ce = rs[0] / rs[1], as_[0] / as_[1]
+            # data parallel: CE terms are already global (their gradient sums to the global gradient);
+            # the BCE mean is local, so it enters with 1/world (ddp.py)
+            total = bce.sum() * (self.world.bce_scale() if self.world is not None else 1.0) + rel_ce + act_ce
+            return dict(total=total, bce=bce.sum().detach(), rel_ce=rel_ce.detach(), act_ce=act_ce.detach(),
+                        rel_err=100.0 - 100.0 * rs[2] / rs[3].clamp(min=1), act_err=100.0 - 100.0 * as_[2] / as_[3].clamp(min=1),
+                        logit=logit, hg_logit=hg_logit, rel_logit=rel_logit, act_logit=act_logit,
+                        rel_idx=(rq, rt), act_idx=(aq, at), rel_grid=rgrid, act_grid=agrid)
+        if a.task_vqa:
+            logit, _ = self.model(b["feat"], b["pos"], input_ids=b["input_ids"], input_masks=b["input_mask"],
+                                  segment_ids=b["segment_ids"])
+        else:
+            logit, _ = self.model(None, None, input_ids=b["input_ids"], input_masks=b["input_mask"],
+                                  segment_ids=b["segment_ids"])
+        bce = ops.bce_with_logits_times_c(logit, b["target"])
+        return dict(total=bce.sum() * (self.world.bce_scale() if self.world is not None else 1.0), bce=bce.sum().detach(),
+                    logit=logit, hg_logit=logit)
+
+    def train_step(self, b):
+        """agqaHGQA.py:262-392 for one device batch."""
+        E = engine()
+        self.model.train()
+        E.begin_step()
+        self.optim.zero_grad(set_to_none=True)
+        if self.world is not None:
+            self.world.begin_step()
+        out = self.forward_losses(b)
+        out["total"].backward()
+        if self.world is not None:
+            self.world.finish()
+        out["grad_norm"] = clip_grad_norm_(self.model.parameters(), 5.0)
+        self.optim.step()
+        return out
+
+    # ------------------------------------------------------------------ loops (agqaHGQA.py:233-455, :459-630)
+    def train(self, train_tuple=None, eval_tuple=None):
+        dset, loader, evaluator = train_tuple or self.train_tuple
+        best = 0.0
+        for epoch in range(self.args.epochs):
+            quesid2ans = {}
+            for i, batch in enumerate(loader):
+                b = batch_to_device(batch, self.device)
+                out = self.train_step(b)
+                if i % self.args.log_freq == 0:
+                    msg = "\nEpoch %d: Total loss= %0.4f \tHGQA loss= %0.4f" % (epoch, out["total"].item(), out["bce"].item())
+                    if "rel_ce" in out:
+                        msg += "\tRel loss= %0.4f \tAct loss= %0.4f\nRel class error= %0.4f \t Act class error= %0.4f" % (
+                            out["rel_ce"].item(), out["act_ce"].item(), out["rel_err"].item(), out["act_err"].item())
+                    print(msg, flush=True)
+                for qid, l in zip(batch["ques_id"].tolist(), out["hg_logit"].argmax(1).cpu().tolist()):
+                    quesid2ans[qid] = l
+            print("Epoch %d: Train %0.2f" % (epoch, evaluator.evaluateOverall(quesid2ans) * 100.0), flush=True)
+            self.save("CURRENT")
+            if eval_tuple is not None:
+                score = self.evaluate(eval_tuple)
+                if score > best:
+                    best = score
+                    self.save("BEST")
+                print("Epoch %d: Valid %0.2f  Best %0.2f" % (epoch, score * 100.0, best * 100.0), flush=True)
+        self.save("LAST")
+
+    @torch.no_grad()
+    def predict(self, eval_tuple, dump=None):
+        dset, loader, evaluator = eval_tuple
+        self.model.eval()
+        quesid2ans = {}
+        for batch in loader:
+            b = batch_to_device(batch, self.device)
+            engine().begin_step()
+            out = self.forward_losses(b)
+            for qid, l in zip(batch["ques_id"].tolist(), out["hg_logit"].argmax(1).cpu().tolist()):
+                quesid2ans[qid] = l
+        return quesid2ans
+
+    def evaluate(self, eval_tuple, dump=None):
+        return eval_tuple.evaluator.evaluateOverall(self.predict(eval_tuple, dump))
+
+    def save(self, name):
+        os.makedirs(self.output, exist_ok=True)
+        torch.save({k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
+                   os.path.join(self.output, "%s.pth" % name))
+
+    def load(self, path):
+        """agqaHGQA.py:864-874: strips DataParallel's `module.` prefix, strict load, refreshes bf16 shadows."""
+        sd = torch.load("%s.pth" % path if not path.endswith(".pth") else path, map_location="cpu")
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        self.model.load_state_dict(sd, strict=True)
+        engine().refresh_shadows()

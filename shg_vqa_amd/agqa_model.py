@@ -1,0 +1,173 @@
+"""AGQAModel and the situation hyper-graph decoder block with the reference's interface
+(AGQA/src/tasks/agqa_model.py:17-269)."""
+import torch
+import torch.nn as nn
+
+from . import modeling as M
+from . import ops
+from .engine import engine
+from .entry import BertTextEncoder, LXRTEncoder, rel_target_mask_device
+from .transformer import TransformerDecoder, TransformerDecoderLayer
+
+MAX_STAR_LENGTH = 40
+
+
+def _head(hid, n_out):
+    return nn.Sequential(nn.Linear(hid, hid * 2), M.GeLU(), M.BertLayerNorm(hid * 2, eps=1e-12), nn.Linear(hid * 2, n_out))
+
+
+def _init_bert_weights(module):
+    """agqa_model.py:152-163 (std hard-coded to 0.02)."""
+    if isinstance(module, (nn.Linear, nn.Embedding)):
+        module.weight.data.normal_(mean=0.0, std=0.02)
+    elif isinstance(module, M.BertLayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+    if isinstance(module, nn.Linear) and module.bias is not None:
+        module.bias.data.zero_()
+
+
+class HGDecoder(nn.Module):
+    """The block the task statement calls "HGDecoder" (agqa_model.py:220-260): query embeddings ->
+    DETR decoder over the visual memory -> class heads, once for relations and once for actions,
+    then the hyper-graph token sequence [B, T*(num_act+num_rel), 768] for the cross encoder.
+
+    forward(memory [B,393,768], rel_segment_ids [B,128], act_segment_ids [B,48])
+        -> rel_preds [B,128,n_rel+1], act_preds [B,48,n_act+1], hg_in [B,176,768]
+    """
+
+    def __init__(self, hid_dim, num_queries, act_queries, num_classes, num_actions, num_situations=16, num_rel=8,
+                 num_act=3, dlayers=5, emb_drop_rate=0.15, decoder_drop_rate=0.15, gt_hg=False):
+        super().__init__()
+        self.hid_dim, self.num_situations, self.num_rel, self.num_act = hid_dim, num_situations, num_rel, num_act
+        self.relation_query_embed = M.HGEmbeddings(num_queries=num_queries, type_vocab_size=16, hidden_size=hid_dim, gt_hg=gt_hg)
+        self.action_query_embed = M.HGEmbeddings(num_queries=act_queries, type_vocab_size=16, hidden_size=hid_dim,
+                                                 hidden_dropout_prob=emb_drop_rate, gt_hg=gt_hg)
+        layer = TransformerDecoderLayer(d_model=hid_dim, nhead=12, dropout=decoder_drop_rate)
+        self.rel_decoder = TransformerDecoder(layer, num_layers=dlayers)
+        self.class_embed = _head(hid_dim, num_classes + 1)
+        self.action_decoder = TransformerDecoder(layer, num_layers=dlayers)
+        self.action_embed = _head(hid_dim, num_actions + 1)
+        self.rel_decoder.apply(_init_bert_weights)
+        self.action_decoder.apply(_init_bert_weights)
+
+    def forward(self, memory, rel_segment_ids, act_segment_ids):
+        B = memory.shape[0]
+        dev = memory.device
+        outs = []
+        for emb, dec, head, seg, per in ((self.relation_query_embed, self.rel_decoder, self.class_embed, rel_segment_ids, self.num_rel),
+                                         (self.action_query_embed, self.action_decoder, self.action_embed, act_segment_ids, self.num_act)):
+            qpos = emb(seg)
+            mask = rel_target_mask_device(self.num_situations, per, dev)
+            out = dec.forward_bf(torch.zeros_like(qpos), memory, qpos, mask)
+            outs.append((out, M.mlp_head(head, out)))
+        (rel_out, rel_preds), (act_out, act_preds) = outs
+        T = self.num_situations
+        hg_in = torch.cat([act_out.view(B, T, -1, self.hid_dim), rel_out.view(B, T, -1, self.hid_dim)], dim=2)
+        return rel_preds, act_preds, hg_in.view(B, -1, self.hid_dim)
+
+
+class _Passthrough(nn.Module):
+    """Stands where the frozen video backbone sits (video_encoder.py:7-51): the hot path starts from
+    precomputed (B,2048,16,7,7) features, so encode() is the identity."""
+
+    def encode(self, x):
+        return x
+
+
+class AGQAModel(nn.Module):
+    def __init__(self, num_answers, num_queries=128, num_classes=456, num_actions=156, model_name="", args=None):
+        super().__init__()
+        if args is None:
+            from .param import hgqa_args
+            args = hgqa_args()
+        self.args = args
+        object.__setattr__(self, "vid_encoder", _Passthrough())     # not registered: no parameters, no keys
+        self.max_seq_length = MAX_STAR_LENGTH
+        self.num_queries = num_queries
+        self.act_queries = args.num_situations * args.num_act
+        if args.task_q:
+            self.bert_encoder = BertTextEncoder(args, max_seq_length=MAX_STAR_LENGTH, mode="lxr")
+            hid = self.bert_encoder.dim
+        elif args.task_vqa:
+            self.lxrt_encoder = LXRTEncoder(args, max_seq_length=MAX_STAR_LENGTH)
+            hid = self.lxrt_encoder.dim
+        elif args.task_hgqa:
+            self.lxrt_encoder = LXRTEncoder(args, max_seq_length=MAX_STAR_LENGTH, mode="lxr")
+            config = self.lxrt_encoder.model.config
+            self.hgq_encoder = M.CrossEncoder(config=config, cross_attn_type=args.cross_attn_type,
+                                              num_max_act=args.num_act, num_max_rel=args.num_rel)
+            hid = self.lxrt_encoder.dim
+            hgd = HGDecoder(hid, self.num_queries, self.act_queries, num_classes, num_actions, args.num_situations,
+                            args.num_rel, args.num_act, args.dlayers, args.emb_drop_rate, args.decoder_drop_rate)
+            # the reference keeps these six modules directly on the model (state_dict keys!)
+            self.relation_query_embed = hgd.relation_query_embed
+            self.action_query_embed = hgd.action_query_embed
+            self.rel_decoder = hgd.rel_decoder
+            self.class_embed = hgd.class_embed
+            self.action_decoder = hgd.action_decoder
+            self.action_embed = hgd.action_embed
+            object.__setattr__(self, "hg_decoder", hgd)
+        else:
+            raise NotImplementedError("task must be one of --taskQ / --taskVQA / --taskHGQA")
+        self.hid_dim = hid
+        self.logit_fc = _head(hid, num_answers)
+        self.logit_fc.apply(_init_bert_weights)
+
+    # ------------------------------------------------------------------ arena / mode plumbing
+    def active_parameter_names(self):
+        """Names (named_parameters) of the tensors that receive gradients for the configured task
+        (under --taskHGQA the x-layers and their pooler get none)."""
+        a = self.args
+        names = []
+        for n, _ in self.named_parameters():
+            if ".cross_attn_layer.self." in n or ".cross_attn_layer.cross_self." in n or ".cross_attn_layer.old." in n:
+                continue
+            if ".pooler_dict." in n and ".pooler_dict.cross." not in n:
+                continue
+            if ".box_fc." in n or ".pos_layer_norm." in n:
+                continue
+            if a.task_hgqa and n.startswith("lxrt_encoder.") and (".cross_attn_layer." in n or ".pooler_dict." in n):
+                continue
+            if a.task_q and ".r_layers." in n:
+                continue
+            names.append(n)
+        return set(names)
+
+    def to_engine(self, compute_dtype=None):
+        """Moves the parameters into the HBM arenas (engine.py).  Call once after construction/loading."""
+        E = engine()
+        if compute_dtype is not None:
+            E.compute_dtype = compute_dtype
+        E.adopt(self, self.active_parameter_names())
+        return self
+
+    def train(self, mode=True):
+        super().train(mode)
+        engine().training = bool(mode)
+        return self
+
+    # ------------------------------------------------------------------ forward (agqa_model.py:166-269)
+    def forward(self, feat, pos, input_ids, input_masks, segment_ids, rel_segment_ids=None, rel_tgt_mask=None,
+                act_segment_ids=None, act_tgt_mask=None, hg_mask=None, rel_tgt_ids=None, act_tgt_ids=None):
+        a = self.args
+        if a.task_q:
+            feats, x, attn = self.bert_encoder((input_ids, input_masks, segment_ids))
+            return M.mlp_head(self.logit_fc, x), attn
+        feat = self.vid_encoder.encode(feat)
+        feats, x, attn = self.lxrt_encoder((input_ids, input_masks, segment_ids), (feat, pos))
+        logit = M.mlp_head(self.logit_fc, x)
+        if a.task_vqa:
+            return logit, attn
+        if a.after_cross_attn_feats:
+            lang_feats, memory = feats[0], feats[1]
+            lang_mask = M.additive_mask(input_masks, input_ids)
+        else:
+            lang_feats, lang_mask, memory, _ = attn[-1]
+        # rel_tgt_mask / act_tgt_mask arguments are ignored like in the reference (agqa_model.py:220, :241)
+        rel_preds, act_preds, hg_in = self.hg_decoder(memory, rel_segment_ids, act_segment_ids)
+        B = memory.shape[0]
+        hgm = hg_mask.view(B, -1) if (a.use_hg_mask and hg_mask is not None) else None
+        x, attn = self.hgq_encoder(lang_feats, lang_mask, hg_in, hgm)
+        hg_logit = M.mlp_head(self.logit_fc, x)
+        return logit, rel_preds, act_preds, hg_logit, attn

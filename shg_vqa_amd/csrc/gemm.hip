@@ -126,6 +126,7 @@ template <typename TC> struct Epilogue {
     int act;
     int accumulate;
     int vec_ok;               // ldc and base pointer allow vector stores of 4 elements
+    TC* pre;                  // optional second output [M, N] (ld = N): the value BEFORE the activation
 };
 
 template <typename TC> __device__ __forceinline__ void store4(TC* p, const float (&v)[4], int n_valid, int vec_ok, int accumulate);
@@ -236,16 +237,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
             const int64_t n = n0 + 64 * wc + 16 * j + 4 * g;
             if (n >= N) continue;
             const int nv = (int)min((int64_t)4, N - n);
-            float v[4];
+            float v[4], u[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = acc[i][j][r];
                 if (ep.bias && r < nv) x += ep.bias[n + r];
+                u[r] = x;
                 if (ep.act == SHG_ACT_GELU) x = gelu_erf(x);
                 else if (ep.act == SHG_ACT_RELU) x = fmaxf(x, 0.f);
                 v[r] = x;
             }
             store4<TC>(crowp + n, v, nv, ep.vec_ok, ep.accumulate);
+            if (ep.pre) store4<TC>(ep.pre + m * N + n, u, nv, (N % 4) == 0, 0);
         }
     }
 }
@@ -340,11 +343,11 @@ extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias
     const int celt = dtype_c == SHG_F32 ? 4 : 2;
     const int vec_ok = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) % (4 * celt)) == 0);
     if (dtype_c == SHG_F32) {
-        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, SHG_ACT_NONE, accumulate, vec_ok};
+        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, SHG_ACT_NONE, accumulate, vec_ok, nullptr};
         return dtype_ab == SHG_F32 ? gemm_dispatch<float, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st)
                                    : gemm_dispatch<bf16_t, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
     }
-    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, SHG_ACT_NONE, 0, vec_ok};
+    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, SHG_ACT_NONE, 0, vec_ok, nullptr};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
 }
 
@@ -373,9 +376,10 @@ extern "C" int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int
 }
 
 extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
-                                   int H, int W, int Cin, int Cout, int act, int pad_out, const void* workspace,
-                                   void* stream) {
+                                   int H, int W, int Cin, int Cout, int act, int pad_out, void* y_pre,
+                                   const void* workspace, void* stream) {
     if (!x || !w || !y) return fail_arg("conv3d_fwd: null pointer");
+    if (y_pre && !al16(y_pre)) return fail_arg("conv3d_fwd: y_pre must be 16-byte aligned");
     if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
     if (!al16(x) || !al16(w) || !al16(y)) return fail_arg("conv3d_fwd: pointers must be 16-byte aligned");
     const int64_t M = (int64_t)B * (T - 4) * H * W, N = Cout, K = (int64_t)45 * Cin;
@@ -386,12 +390,12 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     if (dtype == SHG_F32) {
         ConvRowSrc<float> sa{(const float*)x, pos_in, 0, M, g};
         PlainSrc<float, true> sb{(const float*)w, K, 0, N, K};
-        Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1};
+        Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (float*)y_pre};
         return launch_gemm<float, float>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
     }
     ConvRowSrc<bf16_t> sa{(const bf16_t*)x, pos_in, 0, M, g};
     PlainSrc<bf16_t, true> sb{(const bf16_t*)w, K, 0, N, K};
-    Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1};
+    Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre};
     return launch_gemm<bf16_t, bf16_t>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
 }
 
@@ -405,7 +409,7 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
     const int32_t* pos_in = (const int32_t*)workspace;
     ConvGeom g{Cin, H + 2, W + 2};
     hipStream_t st = (hipStream_t)stream;
-    Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1};
+    Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1, nullptr};
     if (dtype == SHG_F32) {
         PlainSrc<float, false> sa{(const float*)dy, Cout, 0, Cout, Mo};
         ConvColSrc<float> sb{(const float*)x, pos_in, 0, Ncols, Mo, g};

@@ -1,0 +1,158 @@
+"""Runtime context of the HIP path: compute dtype, dropout seed state, and the flat HBM arenas.
+
+MI355X-first memory layout: every parameter of the model lives in ONE contiguous fp32 arena
+(parameters that receive gradients first), with a same-shaped gradient arena, two optimiser-state
+arenas and a bf16 "shadow" arena holding the matrix-core operand copy of every weight at the same
+element offset.  Consequences:
+  * zeroing gradients is one memset, the global gradient norm one reduction, clip + BertAdam + the
+    bf16 re-cast ONE streaming kernel over 289 M elements (reference: a python loop over 576 tensors,
+    lxrt/optimization.py:114-173);
+  * data-parallel gradient exchange works on large contiguous slices of the gradient arena - no
+    flatten/unflatten copies (shg_vqa_amd/ddp.py);
+  * the two (5,3,3) convolution weights are stored channels-last ([Cout,5,3,3,Cin]) - the layout the
+    implicit-GEMM kernel reads - and exposed under the reference's [Cout,Cin,5,3,3] shape as a
+    permuted view, so checkpoints keep the reference's keys and shapes.
+nn.Parameters become views into the arenas; `p.grad` is a persistent view of the gradient arena.
+"""
+import torch
+
+_ENGINE = None
+
+
+def engine():
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = Engine()
+    return _ENGINE
+
+
+def reset_engine(**kw):
+    global _ENGINE
+    _ENGINE = Engine(**kw)
+    return _ENGINE
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class Engine:
+    def __init__(self, compute_dtype=torch.bfloat16, seed=9595, device="cuda"):
+        self.compute_dtype = compute_dtype
+        self.device = torch.device(device)
+        self.seed = seed
+        self._seed_state = None
+        self._stream_id = 0
+        self.param_arena = self.grad_arena = self.m_arena = self.v_arena = self.shadow_arena = None
+        self.n_active = 0
+        self.n_total = 0
+        self.step_state = None
+        self.training = False            # dropout on/off; set by AGQAModel.train()/eval()
+        self.grad_ready_hook = None      # set by ddp: called with (offset, numel) after a gradient write
+        self.model = None
+        self.kernel_events = None        # bench.py: list collecting (start, end) events of the dominant kernel
+        self.pending_clip = None
+
+    # ------------------------------------------------------------------ dropout plumbing
+    @property
+    def seed_state(self):
+        if self._seed_state is None:
+            self._seed_state = torch.tensor([self.seed, 0], dtype=torch.int64, device=self.device)
+        return self._seed_state
+
+    def begin_step(self):
+        """Resets the per-step call-site counter (the device-side step counter is advanced by the
+        optimiser so that hipGraph replays see fresh masks)."""
+        self._stream_id = 0
+
+    def next_stream_id(self):
+        self._stream_id += 1
+        return self._stream_id
+
+    # ------------------------------------------------------------------ arenas
+    def adopt(self, model, active_names):
+        """Moves every parameter of `model` into the arenas.  active_names: set of parameter names
+        (as in named_parameters()) that receive gradients for the configured task."""
+        named = list(model.named_parameters())
+        act = [(n, p) for n, p in named if n in active_names]
+        ina = [(n, p) for n, p in named if n not in active_names]
+        missing = set(active_names) - {n for n, _ in named}
+        if missing:
+            raise KeyError("active parameter names not in the model: %s" % sorted(missing)[:5])
+        offs, off = {}, 0
+        for n, p in act:
+            offs[n] = off
+            off = _round_up(off + p.numel(), 8)          # 8 elements: 16-byte aligned bf16 shadows
+        self.n_active = off
+        for n, p in ina:
+            offs[n] = off
+            off = _round_up(off + p.numel(), 8)
+        self.n_total = off
+        dev = self.device
+        self.param_arena = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.grad_arena = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.m_arena = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.v_arena = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.shadow_arena = torch.zeros(self.n_total, dtype=torch.bfloat16, device=dev)
+        self.step_state = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.offsets = offs
+        for n, p in act + ina:
+            o, k = offs[n], p.numel()
+            store_shape, perm = _storage_layout(p)
+            src = p.detach().to(dev, torch.float32)
+            if perm is not None:
+                src = src.permute(perm)                    # reference layout -> storage layout
+            self.param_arena[o:o + k].view(store_shape).copy_(src)
+            inv = _inverse(perm)
+            p.data = _view(self.param_arena, o, k, store_shape, inv)
+            p._shg_off, p._shg_numel = o, k
+            p._shg_store = self.param_arena[o:o + k].view(store_shape)
+            p._shg_shadow = self.shadow_arena[o:o + k].view(store_shape)
+            if n in active_names:
+                p.grad = _view(self.grad_arena, o, k, store_shape, inv)
+                p._shg_grad = self.grad_arena[o:o + k].view(store_shape)
+            else:
+                p.grad = None
+                p._shg_grad = None
+        self.refresh_shadows()
+        self.model = model
+        return self
+
+    def refresh_shadows(self):
+        """bf16 operand copies of every weight (after loading a checkpoint / initialisation)."""
+        from . import kernels as K
+        K.cast_f32(self.param_arena, self.shadow_arena)
+
+    def operand(self, p):
+        """The tensor a matrix-core kernel should read for parameter p (storage layout)."""
+        return p._shg_shadow if self.compute_dtype == torch.bfloat16 else p._shg_store
+
+    def zero_grad(self):
+        if self.grad_arena is not None:
+            self.grad_arena.zero_()
+
+    def grad_written(self, p):
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(p._shg_off, p._shg_numel)
+
+
+def _storage_layout(p):
+    """(storage shape, permutation reference->storage) ; Conv3d weights are stored channels-last."""
+    if p.dim() == 5:
+        co, ci, kt, kh, kw = p.shape
+        return (co, kt, kh, kw, ci), (0, 2, 3, 4, 1)
+    return tuple(p.shape), None
+
+
+def _inverse(perm):
+    if perm is None:
+        return None
+    inv = [0] * len(perm)
+    for i, j in enumerate(perm):
+        inv[j] = i
+    return tuple(inv)
+
+
+def _view(arena, off, numel, store_shape, inv_perm):
+    v = arena[off:off + numel].view(store_shape)
+    return v.permute(inv_perm) if inv_perm is not None else v

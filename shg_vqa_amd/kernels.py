@@ -304,7 +304,7 @@ def conv_workspace(B, T, H, W, device):
     return ws
 
 
-def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, out_dtype=None):
+def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False):
     """x_cl [B,T,H+2,W+2,Cin] (zero border); w_cl [Cout,5,3,3,Cin]; -> y [B,T-4,H,W,Cout]
     (or written into the interior of a zero-bordered [B,T-4,H+2,W+2,Cout] buffer when pad_out)."""
     _dev(x_cl, w_cl, bias, out)
@@ -319,9 +319,10 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, out
         shape = (B, T - 4, Hp, Wp, cout) if pad_out else (B, T - 4, H, W, cout)
         out = (torch.zeros if pad_out else torch.empty)(shape, dtype=x_cl.dtype, device=x_cl.device)
     _need(out.is_contiguous() and out.dtype == x_cl.dtype, "out must be contiguous and of x's dtype")
+    pre = torch.empty((B, T - 4, H, W, cout), dtype=x_cl.dtype, device=x_cl.device) if want_pre else None
     _lib.call("shg_conv3d_k533_fwd", x_cl.data_ptr(), w_cl.data_ptr(), _p(bias), out.data_ptr(), _dt(x_cl), B, T, H, W, cin,
-              cout, act, 1 if pad_out else 0, ws.data_ptr(), _stream())
-    return out
+              cout, act, 1 if pad_out else 0, _p(pre), ws.data_ptr(), _stream())
+    return (out, pre) if want_pre else out
 
 
 def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False):

@@ -1,0 +1,458 @@
+"""Differentiable ops of the HIP path (torch.autograd.Function wrappers over the C ABI kernels).
+
+Activations flow through autograd; PARAMETER gradients do not: every backward accumulates its
+weight / bias / LayerNorm gradients straight into the fp32 gradient arena (engine.py) with
+accumulate-GEMMs and column-sum kernels and returns None for the parameter inputs.  That removes
+the AccumulateGrad nodes, makes shared weights (the x-layers, mc:1247-1249) work by construction,
+and lets the data-parallel reducer know exactly when a gradient slice is final.
+
+mc = AGQA/src/lxrt/modeling_capsbert.py of the reference.
+"""
+import torch
+
+from . import kernels as K
+from .engine import engine
+
+ACT_NONE, ACT_GELU, ACT_RELU = K.ACT_NONE, K.ACT_GELU, K.ACT_RELU
+
+
+def _cdt():
+    return engine().compute_dtype
+
+
+def _drop_args(p):
+    """(p, seed_state, stream_id) for a call site; p = 0 outside training."""
+    E = engine()
+    if p <= 0.0 or not E.training:
+        return 0.0, None, 0
+    return float(p), E.seed_state, E.next_stream_id()
+
+
+def _acc_vec(partial, param):
+    """grad(param) += column sums held in `partial` [n_partials, cols]."""
+    K.colsum_finish(partial, param._shg_grad.view(-1), True)
+    engine().grad_written(param)
+
+
+def _rows2d(t):
+    return t.reshape(-1, t.shape[-1])
+
+
+def _padded_rows(dy2):
+    """A [M, N] gradient whose rows can be read in 16-byte chunks (pads N to a multiple of 8 with
+    zeros when it is not already backed by such a buffer)."""
+    m, n = dy2.shape
+    np8 = K.pad8(n)
+    if dy2.stride(1) == 1 and dy2.stride(0) % 8 == 0 and dy2.stride(0) >= np8 and dy2.data_ptr() % 16 == 0:
+        return dy2
+    buf = torch.zeros((m, np8), dtype=dy2.dtype, device=dy2.device)
+    buf[:, :n].copy_(dy2)
+    return buf[:, :n]
+
+
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b in the GEMM epilogue).  nn.Linear of mc:373-375, :427, :466, :481."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, weight, bias):
+        E = engine()
+        w = E.operand(weight)
+        x2 = _rows2d(x)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        n = w.shape[0]
+        out = torch.empty((x2.shape[0], n), dtype=x2.dtype, device=x2.device)
+        K.gemm(x2, w, out, None if bias is None else bias._shg_store, True, True)
+        ctx.save_for_backward(x2)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.xshape = x.shape
+        return out.view(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        E = engine()
+        weight, bias = ctx.weight, ctx.bias
+        w = E.operand(weight)
+        dy2 = _padded_rows(_rows2d(dy))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x2.shape, dtype=x2.dtype, device=x2.device)
+            K.gemm(dy2, w, dx, None, True, False)
+            dx = dx.view(ctx.xshape)
+        if weight._shg_grad is not None:
+            K.gemm(dy2, x2, weight._shg_grad, None, False, False, accumulate=True)
+            E.grad_written(weight)
+            if bias is not None:
+                K.colsum(dy2, bias._shg_grad.view(-1), True)
+                E.grad_written(bias)
+        return dx, None, None, None
+
+
+def linear(x, weight, bias=None):
+    """`weight` / `bias`: nn.Parameter or ParamSlice."""
+    return _Linear.apply(x, _anchor(weight), weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------
+class _BiasAct(torch.autograd.Function):
+    """y = dropout(act(x + b)).  mc:472-475 (GELU), transformer.py:230 (ReLU + dropout)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, bias, act, p):
+        p, seed, sid = _drop_args(p)
+        x = x.contiguous()
+        y = K.bias_act_fwd(x, None if bias is None else bias._shg_store, act, p, seed, sid)
+        ctx.save_for_backward(x)
+        ctx.bias, ctx.act, ctx.drop = bias, act, (p, seed, sid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        p, seed, sid = ctx.drop
+        bias = ctx.bias
+        want = bias is not None and bias._shg_grad is not None
+        dx, part = K.bias_act_bwd(x, None if bias is None else bias._shg_store, dy.contiguous(), ctx.act, p, seed, sid,
+                                  want_dbias=want)
+        if want:
+            _acc_vec(part, bias)
+        return dx, None, None, None, None
+
+
+def bias_act(x, bias, act, p_drop=0.0):
+    return _BiasAct.apply(x, None if bias is None else _anchor(bias), bias, act, p_drop)
+
+
+def dropout(x, p_drop):
+    if p_drop <= 0.0 or not engine().training:
+        return x
+    return _BiasAct.apply(x, None, None, ACT_NONE, p_drop)
+
+
+# ------------------------------------------------------------------------------------------------
+class _BiasResLN(torch.autograd.Function):
+    """y = LayerNorm(dropout(act(x + b)) + residual) * gamma + beta.
+    BertAttOutput/BertOutput (mc:431-435, :485-489), decoder norms (transformer.py:220-232),
+    head GELU+LayerNorm (agqa_model.py:105-110), embedding LayerNorms (mc:322, :353)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, bias, residual, gamma, beta, eps, act, p):
+        p, seed, sid = _drop_args(p)
+        x = x.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        y, z, mean, rstd = K.ln_fwd(x, None if bias is None else bias._shg_store, res, gamma._shg_store,
+                                    beta._shg_store, eps, act, p, seed, sid, save_z=True)
+        ctx.save_for_backward(z, mean, rstd, x if act != ACT_NONE else None)
+        ctx.params = (bias, gamma, beta)
+        ctx.cfg = (act, p, seed, sid, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, x = ctx.saved_tensors
+        bias, gamma, beta = ctx.params
+        act, p, seed, sid, has_res = ctx.cfg
+        want_dbias = bias is not None and bias._shg_grad is not None
+        want_dx = ctx.needs_input_grad[0]
+        want_dres = has_res and ctx.needs_input_grad[3]
+        dx, dres, dg, db, dbi = K.ln_bwd(dy.contiguous(), z, x, None if bias is None else bias._shg_store,
+                                         gamma._shg_store, mean, rstd, act, p, seed, sid,
+                                         want_dx=want_dx, want_dres=want_dres, want_dbias=want_dbias)
+        if gamma._shg_grad is not None:
+            _acc_vec(dg, gamma)
+            _acc_vec(db, beta)
+        if want_dbias:
+            _acc_vec(dbi, bias)
+        return (dx if want_dx else None), None, None, dres, None, None, None, None, None
+
+
+def bias_res_layernorm(x, bias, residual, gamma, beta, eps, act=ACT_NONE, p_drop=0.0):
+    return _BiasResLN.apply(x, _anchor(gamma), bias, residual, gamma, beta, eps, act, p_drop)
+
+
+# ------------------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    """softmax(scale * Q K^T + mask) V with dropout on the probabilities (mc:394-421;
+    transformer.py:219-229).  q/k/v may be column slices of fused projection outputs."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, mask_kind, mask, scale, p):
+        p, seed, sid = _drop_args(p)
+        o, lse = K.attention_fwd(q, k, v, heads, mask_kind, mask, scale, p, seed, sid)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.cfg = (heads, mask_kind, mask, scale, p, seed, sid)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        heads, mask_kind, mask, scale, p, seed, sid = ctx.cfg
+        dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+        dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+        K.attention_bwd(q, k, v, o, d_o.contiguous(), lse, dq, dk, dv, heads, mask_kind, mask, scale, p, seed, sid)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attention(q, k, v, heads, mask_kind=K.MASK_NONE, mask=None, scale=0.125, p_drop=0.0):
+    return _Attention.apply(q, k, v, heads, mask_kind, mask, scale, p_drop)
+
+
+# ------------------------------------------------------------------------------------------------
+class _EmbedSum(torch.autograd.Function):
+    """sum_i table_i[ids_i] with nn.Embedding(padding_idx=0) gradient semantics (mc:332-334): rows
+    selected by id 0 receive no gradient.  `whole` tables are added in full (HGEmbeddings uses
+    word_embeddings.weight directly, mc:319, so its row 0 does train)."""
+
+    @staticmethod
+    def forward(ctx, dummy, ids_list, tables, whole):
+        out = None
+        for ids, tab in zip(ids_list, tables):
+            e = tab._shg_store[ids]                      # [B,S,H] for [B,S] ids, [S,H] for [S] ids
+            out = e if out is None else out + e
+        if whole is not None:
+            out = out + whole._shg_store.unsqueeze(0)
+        ctx.ids_list, ctx.tables, ctx.whole = ids_list, tables, whole
+        return out.to(_cdt())
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = dy.float()                                   # [B, S, H]
+        E = engine()
+        for ids, tab in zip(ctx.ids_list, ctx.tables):
+            if tab._shg_grad is None:
+                continue
+            src = g.reshape(-1, g.shape[-1]) if ids.dim() == 2 else g.sum(0)
+            idx = ids.reshape(-1)
+            keep = (idx != 0).unsqueeze(1)
+            tab._shg_grad.index_add_(0, idx, src * keep)
+            E.grad_written(tab)
+        if ctx.whole is not None and ctx.whole._shg_grad is not None:
+            ctx.whole._shg_grad.add_(g.sum(0))
+            E.grad_written(ctx.whole)
+        return None, None, None, None
+
+
+def embed_sum(ids_list, tables, whole=None):
+    """ids broadcastable to [B, S]; returns [B, S, H] in the compute dtype."""
+    dummy = tables[0]          # a Parameter input so that the output takes part in autograd
+    return _EmbedSum.apply(dummy, ids_list, tables, whole)
+
+
+# ------------------------------------------------------------------------------------------------
+class _VisualConvTokens(torch.autograd.Function):
+    """VisualFeatEncoder's conv stack as two implicit-GEMM launches (mc:991-996, :1037-1073):
+    NCDHW fp32 features -> channels-last padded -> conv(5,3,3)+bias+GELU (written straight into the
+    zero-bordered input buffer of the second conv) -> conv+bias+GELU -> tokens [B, 392, C] in (t,h,w)
+    order, then cls token + learned positions.  The feature tensor needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2, cls_token, pe):
+        E = engine()
+        cdt = E.compute_dtype
+        x_cl = K.ncdhw_to_padded_cl(feat.float().contiguous(), cdt)
+        ws = K.conv_workspace(x_cl.shape[0], x_cl.shape[1], x_cl.shape[2] - 2, x_cl.shape[3] - 2, x_cl.device)
+        y1p_buf = torch.zeros((x_cl.shape[0], x_cl.shape[1] - 4, x_cl.shape[2], x_cl.shape[3], w1.shape[0]), dtype=cdt,
+                              device=x_cl.device)
+        evs = getattr(E, "kernel_events", None)
+        if evs is not None:                 # bench.py: time the dominant kernel on the stream it runs on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        y1p, pre1 = K.conv3d_k533_fwd(x_cl, E.operand(w1), b1._shg_store, ACT_GELU, pad_out=True, out=y1p_buf, want_pre=True)
+        if evs is not None:
+            e1.record()
+            evs.append((e0, e1))
+        y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True)
+        B = feat.shape[0]
+        C = y2.shape[-1]
+        tok = y2.view(B, -1, C)
+        n_tok = tok.shape[1] + 1
+        out = torch.empty((B, n_tok, C), dtype=cdt, device=feat.device)
+        pos = pe._shg_store[:n_tok]
+        out[:, 0] = (cls_token._shg_store.view(1, C) + pos[0:1]).to(cdt)
+        out[:, 1:] = (tok.float() + pos[1:].unsqueeze(0)).to(cdt)
+        ctx.save_for_backward(x_cl, y1p, pre1, pre2)
+        ctx.params = (w1, b1, w2, b2, cls_token, pe)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x_cl, y1p, pre1, pre2 = ctx.saved_tensors
+        w1, b1, w2, b2, cls_token, pe = ctx.params
+        E = engine()
+        B, n_tok, C = d_out.shape
+        g32 = d_out.float()
+        if pe._shg_grad is not None:
+            pe._shg_grad[:n_tok].add_(g32.sum(0))
+            E.grad_written(pe)
+        if cls_token._shg_grad is not None:
+            cls_token._shg_grad.view(-1).add_(g32[:, 0].sum(0))
+            E.grad_written(cls_token)
+        d_tok = d_out[:, 1:].contiguous().view(pre2.shape)
+        # conv2: GELU', bias grad, weight grad, input grad
+        d2, part = K.bias_act_bwd(pre2, None, d_tok, ACT_GELU, want_dbias=True)
+        _acc_vec(part, b2)
+        K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+        E.grad_written(w2)
+        # input gradient of conv2 = the same forward kernel on dy padded by (4 in T, 1 in H/W) with the
+        # weight flipped and transposed: Wd[ci][kt'][kh'][kw'][co] = W[co][4-kt'][2-kh'][2-kw'][ci]
+        d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
+        wd = E.operand(w2).flip(1, 2, 3).permute(4, 1, 2, 3, 0).contiguous()
+        d_y1 = K.conv3d_k533_fwd(d2p, wd, None, ACT_NONE, pad_out=False)
+        d1, part1 = K.bias_act_bwd(pre1, None, d_y1, ACT_GELU, want_dbias=True)
+        _acc_vec(part1, b1)
+        K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
+        E.grad_written(w1)
+        return None, None, None, None, None, None, None
+
+
+def visual_conv_tokens(feat, w1, b1, w2, b2, cls_token, pe):
+    return _VisualConvTokens.apply(feat, w1, b1, w2, b2, cls_token, pe)
+
+
+# ------------------------------------------------------------------------------------------------
+class _AddParamRows(torch.autograd.Function):
+    """x [B, S, H] + rows [S, H] built from small parameters (type tokens / cls tokens of
+    CrossEncoder, mc:1168-1181).  `builder` maps the parameters to the [S, H] fp32 addend; its
+    gradient goes back through `scatter` (a function dsum [S,H] -> None that accumulates)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, addend, scatter):
+        ctx.scatter = scatter
+        return (x.float() + addend.unsqueeze(0)).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.scatter(dy.float().sum(0))
+        return dy, None, None, None
+
+
+def add_param_rows(x, anchor, addend, scatter):
+    return _AddParamRows.apply(x, anchor, addend, scatter)
+
+
+class _PrependParamRow(torch.autograd.Function):
+    """cat([row.expand(B,1,H), x], dim=1) for a [1,1,H] parameter row (cls tokens, mc:1183-1184)."""
+
+    @staticmethod
+    def forward(ctx, x, row_param):
+        B, S, H = x.shape
+        out = torch.empty((B, S + 1, H), dtype=x.dtype, device=x.device)
+        out[:, 0] = row_param._shg_store.view(1, H).to(x.dtype)
+        out[:, 1:] = x
+        ctx.row_param = row_param
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        rp = ctx.row_param
+        if rp._shg_grad is not None:
+            rp._shg_grad.view(-1).add_(dy[:, 0].float().sum(0))
+            engine().grad_written(rp)
+        return dy[:, 1:], None
+
+
+def prepend_param_row(x, row_param):
+    return _PrependParamRow.apply(x, row_param)
+
+
+# ------------------------------------------------------------------------------------------------
+class _SetLoss(torch.autograd.Function):
+    """Hungarian matching + class-weighted CE over all query slots, fused on the device
+    (matcher.py:62-80 + agqaHGQA.py:203-229).  Returns (loss_sums [4], grid, query_idx, target_idx);
+    loss = sums[0] / sums[1] is formed by the caller so that data-parallel runs can all-reduce the
+    numerator and denominator first."""
+
+    @staticmethod
+    def forward(ctx, logits, tgt, tgt_len, class_weight, per_frame):
+        B, Q, C = logits.shape
+        n_frames = B * (Q // per_frame)
+        lg = logits.contiguous().view(n_frames, per_frame, C)
+        oq, ot, grid = K.hungarian_per_frame(lg, tgt.view(n_frames, per_frame), tgt_len.view(n_frames))
+        rows = lg.view(-1, C)
+        stats, sums = K.weighted_ce_fwd(rows, grid.view(-1), class_weight)
+        ctx.save_for_backward(rows, grid, stats, sums, class_weight)
+        ctx.shape = (B, Q, C)
+        ctx.mark_non_differentiable(grid, oq, ot)
+        return sums, grid, oq, ot
+
+    @staticmethod
+    def backward(ctx, d_sums, *_):
+        rows, grid, stats, sums, cw = ctx.saved_tensors
+        B, Q, C = ctx.shape
+        # upstream gradient arrives on sums[0] (the numerator); the caller divides by sums[1]:
+        # d loss / d numerator = 1 / sums[1] is already folded into the kernel, so pass d_sums[0]*sums[1]
+        gscale = (d_sums[0] * sums[1]).reshape(1).float().contiguous()
+        d = K.weighted_ce_bwd(rows, grid.view(-1), cw, stats, sums, gscale, padded=True)
+        return d.view(B, Q, -1)[:, :, :C], None, None, None, None
+
+
+def set_loss(logits, tgt, tgt_len, class_weight, per_frame):
+    return _SetLoss.apply(logits, tgt, tgt_len, class_weight, per_frame)
+
+
+class _BCELoss(torch.autograd.Function):
+    """BCEWithLogitsLoss(mean) * n_classes (agqaHGQA.py:344-345)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        lg = logits.contiguous()
+        one = torch.ones(1, dtype=torch.float32, device=lg.device)
+        loss, d = K.bce_logits(lg, target.contiguous(), one, want_grad=True, padded=True)
+        ctx.save_for_backward(d)
+        ctx.c = lg.shape[1]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        out = d if g is None else (d.float() * g.float()).to(d.dtype)
+        return out[:, :ctx.c], None
+
+
+def bce_with_logits_times_c(logits, target):
+    return _BCELoss.apply(logits, target)
+
+
+# ------------------------------------------------------------------------------------------------
+class ParamSlice:
+    """Rows r0:r1 of a parameter (e.g. the q/k/v blocks of nn.MultiheadAttention.in_proj_weight,
+    transformer.py:192-193) presented to the ops like a parameter of its own."""
+
+    def __init__(self, base, r0, r1):
+        self.base, self.r0, self.r1 = base, r0, r1
+        self.shape = (r1 - r0,) + tuple(base.shape[1:])
+
+    @property
+    def _row(self):
+        n = 1
+        for s in self.base.shape[1:]:
+            n *= s
+        return n
+
+    @property
+    def _shg_store(self):
+        return self.base._shg_store[self.r0:self.r1]
+
+    @property
+    def _shg_shadow(self):
+        return self.base._shg_shadow[self.r0:self.r1]
+
+    @property
+    def _shg_grad(self):
+        g = self.base._shg_grad
+        return None if g is None else g[self.r0:self.r1]
+
+    @property
+    def _shg_off(self):
+        return self.base._shg_off + self.r0 * self._row
+
+    @property
+    def _shg_numel(self):
+        return (self.r1 - self.r0) * self._row
+
+
+def _anchor(p):
+    return p.base if isinstance(p, ParamSlice) else p

@@ -364,7 +364,10 @@ def _gemm_case(K, dtype, akm, bkm, M, N, Kd, accumulate, out_dtype, with_bias):
 def test_gemm_layouts_and_tails(K, dtype, akm, bkm):
     # the non-contracted extent of a K-strided operand is its contiguous dimension: keep it 16-byte
     # aligned (the model only ever has hidden sizes there); the contracted extent may be anything
-    for (M, N, Kd) in [(1280, 768, 768), (784, 3072, 786), (136, 456, 200), (64, 8, 64), (8, 136, 1001 if (akm and bkm) is False and not (akm or bkm) else 1000)]:
+    sizes = [(1280, 768, 768), (784, 3072, 776), (136, 456, 200), (64, 8, 64), (8, 136, 1000)]
+    if not akm and not bkm:
+        sizes.append((264, 72, 1001))          # wgrad form: the contracted extent (rows) may be ragged
+    for (M, N, Kd) in sizes:
         _gemm_case(K, dtype, akm, bkm, M, N, Kd, False, torch.float32, with_bias=(M % 16 == 0))
         if dtype == torch.bfloat16:
             _gemm_case(K, dtype, akm, bkm, M, N, Kd, False, torch.bfloat16, with_bias=True)
