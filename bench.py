@@ -41,7 +41,7 @@ def synthetic_device_batches(n_batches, bsz, seed, device):
     return out
 
 
-def cpu_baseline(bsz=4, timed=2):
+def cpu_baseline(bsz=4, timed=4):
     """The CPU oracle's full train step (same arithmetic, fp32, dropout on) on this box's host cores."""
     from oracle import shg_ref
     # the box's CPU share, not the host's core count (oversubscribing the cgroup makes MKL crawl)

@@ -165,6 +165,8 @@ int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o
  *   a_kmajor = 1: A stored [M, K] (lda = row stride);  0: A stored [K, M]
  *   b_kmajor = 1: B stored [N, K] (ldb = row stride);  0: B stored [K, N]
  *   C (dtype_c: SHG_F32 or SHG_BF16) row stride ldc; accumulate != 0 adds into C (fp32 C only).
+ *   Weight-gradient shapes (both operands contraction-strided, accumulate) with few output tiles are
+ *   split along K over several workgroups whose partial sums are added with fp32 atomics.
  *   forward  y = x W^T : a_kmajor=1 (x), b_kmajor=1 (W [N,K])
  *   dgrad   dx = dy W  : a_kmajor=1 (dy [M,N]), b_kmajor=0 (W [N,K] read as [Kred=N][K])
  *   wgrad   dW = dy^T x: a_kmajor=0 (dy [M,N] as [Kred=M][N]), b_kmajor=0 (x [M,K] as [Kred=M][K])
@@ -183,9 +185,9 @@ int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype
  *      spatially padded [B, T-4, H+2, W+2, Cout] buffer (border untouched, must be pre-zeroed);
  *      y_pre (optional) [B, T-4, H, W, Cout] receives conv + bias before the activation (needed by backward)
  *   wgrad: dw [Cout,5,3,3,Cin] fp32 (+= when accumulate), dy [B,T-4,H,W,Cout] (dtype)
- *   The input gradient is the same forward kernel applied to dy zero-padded by 4 in T and 1 in H/W
- *   with the weight flipped and transposed ([Cin][4-kt][2-kh][2-kw][Cout]); the host does that
- *   re-layout (shg_vqa_amd/ops.py).
+ *   dgrad: dx [B,Tp-4,H,W,Cin] from dy_padded [B,Tp,H+2,W+2,Cout] = dy zero-padded by 4 in T and 1 in H/W
+ *          (Tp = T_out + 8): the forward gather over dy_padded with the weight read flipped and
+ *          "contraction strided" straight from w [Cout,5,3,3,Cin] - no transposed weight copy.
  *   workspace: shg_conv3d_k533_workspace_bytes(B,T,H,W) bytes, filled once per shape by
  *   shg_conv3d_k533_prepare (gather tables: position of every output row in the padded tensors).
  */
@@ -196,6 +198,8 @@ int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y
                         void* stream);
 int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                           int Cin, int Cout, int accumulate, const void* workspace, void* stream);
+int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
+                          int Cin, int Cout, const void* workspace, void* stream);
 /* NCDHW fp32 features -> channels-last, spatially zero-padded (dtype) : [B,C,T,H,W] -> [B,T,H+2,W+2,C] */
 int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int T, int H, int W, void* stream);
 

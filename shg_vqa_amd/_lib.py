@@ -39,6 +39,7 @@ _SIGNATURES = {
     "shg_conv3d_k533_prepare": ([P, I, I, I, I, P], c_int),
     "shg_conv3d_k533_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P], c_int),
     "shg_conv3d_k533_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, P, P], c_int),
+    "shg_conv3d_k533_dgrad": ([P, P, P, I, I, I, I, I, I, I, P, P], c_int),
     "shg_ncdhw_to_padded_cl": ([P, P, I, I, I, I, I, I, P], c_int),
     "shg_sumsq": ([P, L, P, I, P, P], c_int),
     "shg_bertadam_arena": ([P, P, P, P, P, L, P, F, F, F, L, F, F, F, F, P, I, P], c_int),

@@ -19,6 +19,9 @@
 // channels-last tensor.
 #include <math.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "mma.h"
 
 namespace shg {
@@ -115,6 +118,27 @@ template <typename T> struct ConvColSrc {
     }
 };
 
+// B operand of the conv INPUT gradient, read straight from the forward weight W[co][tap][ci]:
+// contraction index k = (tap', co) with tap' the flipped tap (44 - tap), columns n = ci.  For a fixed
+// tap' this is a [co][ci] matrix with row stride 45*Cin - "contraction strided" - so the flipped,
+// transposed weight copy of a textbook conv-transpose is never materialised.
+template <typename T> struct ConvWeightColSrc {
+    static constexpr bool KMAJOR = false;
+    const T* w;
+    int64_t r0, R, K;         // R = Cin (columns), K = 45 * Cout
+    int Cin, Cout;
+    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
+        const int64_t k = k0 + row;
+        const int64_t c = r0 + 64 * t + ch * Tile64<T>::EPC;
+        ok = k < K && c < R;
+        const int64_t kk = ok ? k : 0;
+        const int tapf = 44 - (int)(kk / Cout);
+        const int64_t co = kk % Cout;
+        return w + (co * 45 + tapf) * (int64_t)Cin + c;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // epilogue description
 // ---------------------------------------------------------------------------------------------
@@ -127,26 +151,93 @@ template <typename TC> struct Epilogue {
     int accumulate;
     int vec_ok;               // ldc and base pointer allow vector stores of 4 elements
     TC* pre;                  // optional second output [M, N] (ld = N): the value BEFORE the activation
+    int atomic;               // split-K: fp32 atomic adds into C (C must hold the running sum already)
 };
 
-template <typename TC> __device__ __forceinline__ void store4(TC* p, const float (&v)[4], int n_valid, int vec_ok, int accumulate);
-template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4], int n_valid, int vec_ok, int accumulate) {
-    if (n_valid == 4 && vec_ok) {
-        f32x4 o = {v[0], v[1], v[2], v[3]};
-        if (accumulate) o += *reinterpret_cast<f32x4*>(p);
-        *reinterpret_cast<f32x4*>(p) = o;
-    } else {
-        for (int r = 0; r < n_valid; ++r) p[r] = accumulate ? p[r] + v[r] : v[r];
-    }
+constexpr int STG_LD = 68;                         // fp32 row stride of the epilogue staging tile (64 + 4 pad)
+constexpr int STG_BYTES = 4 * 64 * STG_LD * 4;     // one 64 x 64 staging tile per wave
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == SHG_ACT_GELU) return gelu_erf(x);
+    if (act == SHG_ACT_RELU) return fmaxf(x, 0.f);
+    return x;
 }
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4], int n_valid, int vec_ok, int) {
-    if (n_valid == 4 && vec_ok) {
-        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<bf16x4*>(p) = o;
-    } else {
-        for (int r = 0; r < n_valid; ++r) p[r] = (bf16_t)v[r];
+
+// Writes one wave's 64 x 64 result (staged in LDS as fp32 [64][STG_LD]) to global memory in whole
+// 128/256-byte row segments.
+template <typename TC> struct RowWriter;
+template <> struct RowWriter<bf16_t> {
+    __device__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
+                               int64_t N, int lane) {
+#pragma unroll 2
+        for (int p = 0; p < 8; ++p) {
+            const int row = 8 * p + (lane >> 3), col = (lane & 7) * 8;
+            const int64_t m = mbase + row, n = nbase + col;
+            if (m >= M || n >= N) continue;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col + 4);
+            float u[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            const int nv = (int)min((int64_t)8, N - n);
+            if (ep.bias)
+                for (int r = 0; r < nv; ++r) u[r] += ep.bias[n + r];
+            const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
+            bf16_t* dst = ep.c + crow * ep.ldc + n;
+            bf16_t* pre = ep.pre ? ep.pre + m * N + n : nullptr;
+            if (nv == 8 && ep.vec_ok) {
+                bf16x8 o, q;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { q[r] = (bf16_t)u[r]; o[r] = (bf16_t)apply_act(u[r], ep.act); }
+                *reinterpret_cast<bf16x8*>(dst) = o;
+                if (pre) *reinterpret_cast<bf16x8*>(pre) = q;
+            } else {
+                for (int r = 0; r < nv; ++r) {
+                    dst[r] = (bf16_t)apply_act(u[r], ep.act);
+                    if (pre) pre[r] = (bf16_t)u[r];
+                }
+            }
+        }
     }
-}
+};
+template <> struct RowWriter<float> {
+    __device__ static void run(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
+                               int64_t N, int lane) {
+        if (ep.atomic) {                               // one 256-byte row segment per wave instruction
+            const int64_t n = nbase + lane;
+            for (int row = 0; row < 64; ++row) {
+                const int64_t m = mbase + row;
+                if (m < M && n < N) atomicAdd(ep.c + m * ep.ldc + n, stage[row * STG_LD + lane]);
+            }
+            return;
+        }
+#pragma unroll 2
+        for (int p = 0; p < 16; ++p) {
+            const int row = 4 * p + (lane >> 4), col = (lane & 15) * 4;
+            const int64_t m = mbase + row, n = nbase + col;
+            if (m >= M || n >= N) continue;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
+            float u[4] = {a[0], a[1], a[2], a[3]};
+            const int nv = (int)min((int64_t)4, N - n);
+            if (ep.bias)
+                for (int r = 0; r < nv; ++r) u[r] += ep.bias[n + r];
+            const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
+            float* dst = ep.c + crow * ep.ldc + n;
+            float* pre = ep.pre ? ep.pre + m * N + n : nullptr;
+            if (nv == 4 && ep.vec_ok) {
+                f32x4 o = {apply_act(u[0], ep.act), apply_act(u[1], ep.act), apply_act(u[2], ep.act), apply_act(u[3], ep.act)};
+                if (ep.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = o;
+                if (pre && (N % 4) == 0) *reinterpret_cast<f32x4*>(pre) = f32x4{u[0], u[1], u[2], u[3]};
+                else if (pre) for (int r = 0; r < 4; ++r) pre[r] = u[r];
+            } else {
+                for (int r = 0; r < nv; ++r) {
+                    const float x = apply_act(u[r], ep.act);
+                    dst[r] = ep.accumulate ? dst[r] + x : x;
+                    if (pre) pre[r] = u[r];
+                }
+            }
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // the kernel
@@ -198,11 +289,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
         }
     };
 
-    const int64_t nk = (K + BK - 1) / BK;
-    fetch(0);
+    const int64_t nk_all = (K + BK - 1) / BK;
+    const int64_t per_split = (nk_all + gridDim.y - 1) / gridDim.y;
+    const int64_t kt_begin = (int64_t)blockIdx.y * per_split;
+    const int64_t nk = min(nk_all, kt_begin + per_split);
+    if (kt_begin >= nk) return;                       // whole block: nothing to add
+    fetch(kt_begin * BK);
     commit();
     __syncthreads();
-    for (int64_t kt = 0; kt < nk; ++kt) {
+    for (int64_t kt = kt_begin; kt < nk; ++kt) {
         if (kt + 1 < nk) fetch((kt + 1) * BK);
         const char* tA = ldsA + wr * TL::BYTES;
         const char* tB = ldsB + wc * TL::BYTES;
@@ -225,40 +320,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
         __syncthreads();
     }
 
-    // epilogue: lane holds, for output row m = .. + li, the 4 consecutive columns n = .. + 4g + r
+    // epilogue: stage the wave's 64 x 64 fp32 result in LDS (the operand tiles are dead after the last
+    // barrier of the loop) and write whole row segments
+    float* stage = reinterpret_cast<float*>(smem) + wave * (64 * STG_LD);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + 64 * wr + 16 * i + li;
-        if (m >= M) continue;
-        const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
-        TC* crowp = ep.c + crow * ep.ldc;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + 64 * wc + 16 * j + 4 * g;
-            if (n >= N) continue;
-            const int nv = (int)min((int64_t)4, N - n);
-            float v[4], u[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r];
-                if (ep.bias && r < nv) x += ep.bias[n + r];
-                u[r] = x;
-                if (ep.act == SHG_ACT_GELU) x = gelu_erf(x);
-                else if (ep.act == SHG_ACT_RELU) x = fmaxf(x, 0.f);
-                v[r] = x;
-            }
-            store4<TC>(crowp + n, v, nv, ep.vec_ok, ep.accumulate);
-            if (ep.pre) store4<TC>(ep.pre + m * N + n, u, nv, (N % 4) == 0, 0);
-        }
-    }
+        for (int j = 0; j < 4; ++j)      // acc[i][j]: row (m) = 16 i + li, columns (n) = 16 j + 4 g + r
+            *reinterpret_cast<f32x4*>(stage + (16 * i + li) * STG_LD + 16 * j + 4 * g) = acc[i][j];
+    __syncthreads();
+    RowWriter<TC>::run(stage, ep, m0 + 64 * wr, n0 + 64 * wc, M, N, lane);
 }
 
 template <typename T, typename TC, typename SrcA, typename SrcB>
-static int launch_gemm(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what) {
+static int launch_gemm(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
+                       bool allow_split = false) {
     const int64_t gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
     if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
-    const size_t lds = 4 * Tile64<T>::BYTES;
-    hipLaunchKernelGGL((gemm_kernel<T, TC, SrcA, SrcB>), dim3((unsigned)(gm * gn)), dim3(256), lds, st, sa, sb, ep, M, N, K, (int)gm);
+    const size_t lds = std::max<size_t>(4 * Tile64<T>::BYTES, STG_BYTES);
+    // split-K (weight gradients: few output tiles, very long contraction): aim at >= 2 tiles per CU while
+    // keeping >= 4 K-steps per split; partial sums are added with fp32 atomics into the running C.
+    int split = 1;
+    const int64_t nk = (K + BK - 1) / BK;
+    if (allow_split && ep.accumulate && gm * gn < 384) {
+        split = (int)std::min<int64_t>((512 + gm * gn - 1) / (gm * gn), std::max<int64_t>(1, nk / 4));
+        if (split > 1) ep.atomic = 1;
+    }
+    hipLaunchKernelGGL((gemm_kernel<T, TC, SrcA, SrcB>), dim3((unsigned)(gm * gn), split), dim3(256), lds, st, sa, sb, ep, M, N,
+                       K, (int)gm);
     return check_launch(what);
 }
 
@@ -273,7 +362,8 @@ static int gemm_dispatch(const void* a, const void* b, Epilogue<TC> ep, int64_t 
         return launch_gemm<T, TC>(PlainSrc<T, true>{A, lda, 0, M, K}, PlainSrc<T, false>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_nn");
     if (!a_kmajor && b_kmajor)
         return launch_gemm<T, TC>(PlainSrc<T, false>{A, lda, 0, M, K}, PlainSrc<T, true>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_tt");
-    return launch_gemm<T, TC>(PlainSrc<T, false>{A, lda, 0, M, K}, PlainSrc<T, false>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_tn");
+    return launch_gemm<T, TC>(PlainSrc<T, false>{A, lda, 0, M, K}, PlainSrc<T, false>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_tn",
+                              std::is_same<TC, float>::value);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,14 +430,14 @@ extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias
     const int64_t ea = ((a_kmajor ? K : M) + epc - 1) / epc * epc, eb = ((b_kmajor ? K : N) + epc - 1) / epc * epc;
     if (lda < ea || ldb < eb || ldc < N) return fail_arg("gemm: leading dimension too small for 16-byte row reads");
     hipStream_t st = (hipStream_t)stream;
-    const int celt = dtype_c == SHG_F32 ? 4 : 2;
-    const int vec_ok = (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) % (4 * celt)) == 0);
+    const int vlen = dtype_c == SHG_F32 ? 4 : 8;      // elements per 16-byte output vector
+    const int vec_ok = (ldc % vlen == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
     if (dtype_c == SHG_F32) {
-        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, SHG_ACT_NONE, accumulate, vec_ok, nullptr};
+        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, SHG_ACT_NONE, accumulate, vec_ok, nullptr, 0};
         return dtype_ab == SHG_F32 ? gemm_dispatch<float, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st)
                                    : gemm_dispatch<bf16_t, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
     }
-    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, SHG_ACT_NONE, 0, vec_ok, nullptr};
+    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, SHG_ACT_NONE, 0, vec_ok, nullptr, 0};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
 }
 
@@ -390,12 +480,12 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     if (dtype == SHG_F32) {
         ConvRowSrc<float> sa{(const float*)x, pos_in, 0, M, g};
         PlainSrc<float, true> sb{(const float*)w, K, 0, N, K};
-        Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (float*)y_pre};
+        Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (float*)y_pre, 0};
         return launch_gemm<float, float>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
     }
     ConvRowSrc<bf16_t> sa{(const bf16_t*)x, pos_in, 0, M, g};
     PlainSrc<bf16_t, true> sb{(const bf16_t*)w, K, 0, N, K};
-    Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre};
+    Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre, 0};
     return launch_gemm<bf16_t, bf16_t>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
 }
 
@@ -409,7 +499,7 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
     const int32_t* pos_in = (const int32_t*)workspace;
     ConvGeom g{Cin, H + 2, W + 2};
     hipStream_t st = (hipStream_t)stream;
-    Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1, nullptr};
+    Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1, nullptr, 0};
     if (dtype == SHG_F32) {
         PlainSrc<float, false> sa{(const float*)dy, Cout, 0, Cout, Mo};
         ConvColSrc<float> sb{(const float*)x, pos_in, 0, Ncols, Mo, g};
@@ -418,6 +508,30 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
     PlainSrc<bf16_t, false> sa{(const bf16_t*)dy, Cout, 0, Cout, Mo};
     ConvColSrc<bf16_t> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
     return launch_gemm<bf16_t, float>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+}
+
+extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
+                                     int Cin, int Cout, const void* workspace, void* stream) {
+    // dx[b,t,h,w,ci] = sum_{tap',co} dYp[b, t+kt', h+kh', w+kw', co] * W[co][44-tap'][ci]; dYp = dy padded by
+    // 4 in T and 1 in H/W, so this is the forward gather over dYp with the weight read "contraction strided".
+    if (!dy_padded || !w || !dx) return fail_arg("conv3d_dgrad: null pointer");
+    if (int e = conv_check(dtype, B, Tp, H, W, Cout, Cin, workspace)) return e;    // the gathered tensor has Cout channels
+    if (Cin % 8) return fail_arg("conv3d_dgrad: Cin must be a multiple of 8");
+    if (!al16(dy_padded) || !al16(w) || !al16(dx)) return fail_arg("conv3d_dgrad: pointers must be 16-byte aligned");
+    const int64_t M = (int64_t)B * (Tp - 4) * H * W, N = Cin, K = (int64_t)45 * Cout;
+    const int32_t* pos_in = (const int32_t*)workspace;
+    ConvGeom g{Cout, H + 2, W + 2};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) {
+        ConvRowSrc<float> sa{(const float*)dy_padded, pos_in, 0, M, g};
+        ConvWeightColSrc<float> sb{(const float*)w, 0, N, K, Cin, Cout};
+        Epilogue<float> ep{(float*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
+        return launch_gemm<float, float>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
+    }
+    ConvRowSrc<bf16_t> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
+    ConvWeightColSrc<bf16_t> sb{(const bf16_t*)w, 0, N, K, Cin, Cout};
+    Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
+    return launch_gemm<bf16_t, bf16_t>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
 }
 
 extern "C" int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int T, int H, int W, void* stream) {

@@ -300,13 +300,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     partial[(int64_t)blockIdx.y * cols + c] = acc;
 }
 
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int n_partials, int cols,
-                                                            float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// second stage of the column reductions: block = 64 columns x 16 partial-row groups
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int n_partials, int cols,
+                                                             float* __restrict__ out, int accumulate) {
+    __shared__ float sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int p = 0; p < n_partials; ++p) s += partial[(int64_t)p * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int p = ty; p < n_partials; p += 16) s += partial[(int64_t)p * cols + c];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][tx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 template <typename T> static bool aligned16(const T* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -380,7 +390,7 @@ extern "C" int shg_colsum_partial(const void* x, int dtype, int64_t rows, int co
 
 extern "C" int shg_colsum_finish(const float* partial, int n_partials, int cols, float* out, int accumulate, void* stream) {
     if (!partial || !out || n_partials < 1 || cols < 1) return fail_arg("colsum_finish: bad argument");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial,
                        n_partials, cols, out, accumulate);
     return check_launch("colsum_finish");
 }

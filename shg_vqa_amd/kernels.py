@@ -340,6 +340,21 @@ def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False):
     return dw
 
 
+def conv3d_k533_dgrad(dy_padded, w_cl):
+    """dy_padded [B,To+8,H+2,W+2,Cout] (dy zero-padded by 4 in T, 1 in H/W); w_cl [Cout,5,3,3,Cin] -> dx [B,To+4,H,W,Cin]."""
+    _dev(dy_padded, w_cl)
+    _need(dy_padded.dim() == 5 and dy_padded.is_contiguous() and w_cl.is_contiguous(), "contiguous channels-last tensors")
+    B, Tp, Hp, Wp, cout = dy_padded.shape
+    H, W = Hp - 2, Wp - 2
+    cin = w_cl.shape[4]
+    _need(tuple(w_cl.shape) == (cout, 5, 3, 3, cin) and w_cl.dtype == dy_padded.dtype, "weight must be [Cout,5,3,3,Cin] of dy's dtype")
+    ws = conv_workspace(B, Tp, H, W, dy_padded.device)
+    dx = torch.empty((B, Tp - 4, H, W, cin), dtype=dy_padded.dtype, device=dy_padded.device)
+    _lib.call("shg_conv3d_k533_dgrad", dy_padded.data_ptr(), w_cl.data_ptr(), dx.data_ptr(), _dt(dy_padded), B, Tp, H, W, cin,
+              cout, ws.data_ptr(), _stream())
+    return dx
+
+
 def ncdhw_to_padded_cl(x, dtype):
     """[B,C,T,H,W] fp32 -> [B,T,H+2,W+2,C] `dtype`, zero border."""
     _dev(x)

@@ -296,11 +296,10 @@ class _VisualConvTokens(torch.autograd.Function):
         _acc_vec(part, b2)
         K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
         E.grad_written(w2)
-        # input gradient of conv2 = the same forward kernel on dy padded by (4 in T, 1 in H/W) with the
-        # weight flipped and transposed: Wd[ci][kt'][kh'][kw'][co] = W[co][4-kt'][2-kh'][2-kw'][ci]
+        # input gradient of conv2 = the forward gather over dy padded by (4 in T, 1 in H/W); the kernel reads
+        # the weight flipped / transposed in place
         d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
-        wd = E.operand(w2).flip(1, 2, 3).permute(4, 1, 2, 3, 0).contiguous()
-        d_y1 = K.conv3d_k533_fwd(d2p, wd, None, ACT_NONE, pad_out=False)
+        d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2))
         d1, part1 = K.bias_act_bwd(pre1, None, d_y1, ACT_GELU, want_dbias=True)
         _acc_vec(part1, b1)
         K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)

@@ -433,3 +433,34 @@ def test_conv3d_k533_fwd_wgrad_vs_torch(K, dtype, B, T, H, W, Cin, Cout):
     dw2 = dw.clone()
     K.conv3d_k533_wgrad(x_cl, dy.permute(0, 2, 3, 4, 1).contiguous().to(dtype).to(DEV), dw2, accumulate=True)
     assert torch.allclose(dw2, 2 * dw, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_k533_dgrad_vs_torch(K, dtype):
+    gen = torch.Generator().manual_seed(21)
+    B, T, H, W, Cin, Cout = 2, 12, 7, 7, 64, 128
+    x = torch.randn(B, Cin, T, H, W, generator=gen).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 5, 3, 3, generator=gen) / math.sqrt(Cin * 45)).to(dtype).float()
+    y = F.conv3d(F.pad(x, (1, 1, 1, 1)), w)
+    dy = torch.randn(y.shape, generator=gen).to(dtype).float()
+    y.backward(dy)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(dtype).to(DEV)            # [B,To,H,W,Cout]
+    dyp = F.pad(dy_cl, (0, 0, 1, 1, 1, 1, 4, 4))
+    w_cl = w.permute(0, 2, 3, 4, 1).contiguous().to(dtype).to(DEV)
+    dx = K.conv3d_k533_dgrad(dyp, w_cl)                                          # [B,T,H,W,Cin]
+    got = dx.float().cpu().permute(0, 4, 1, 2, 3)
+    rt = 2e-4 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(got, x.grad, rtol=rt, atol=rt * x.grad.abs().max().item()), (got - x.grad).abs().max()
+
+
+def test_gemm_split_k_accumulates_into_running_sum(K):
+    """Weight-gradient form with few output tiles: split along K, fp32 atomics into C."""
+    gen = torch.Generator().manual_seed(8)
+    Mred, N1, N2 = 12576, 768, 256
+    dy = torch.randn(Mred, N1, generator=gen).to(torch.bfloat16)
+    x = torch.randn(Mred, N2, generator=gen).to(torch.bfloat16)
+    c0 = torch.randn(N1, N2, generator=gen)
+    ref = c0 + dy.float().t() @ x.float()
+    out = c0.clone().to(DEV)
+    K.gemm(dy.to(DEV), x.to(DEV), out, None, False, False, accumulate=True)
+    assert torch.allclose(out.cpu(), ref, rtol=2e-3, atol=0.5), (out.cpu() - ref).abs().max()
