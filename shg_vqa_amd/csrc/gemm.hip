@@ -32,14 +32,17 @@ template <typename T> struct Stage {
     static constexpr int NCH = (128 * 64 * (int)sizeof(T)) / 16 / 256;   // 16-byte chunks per thread per operand
 };
 
-// Decomposes a thread's i-th staged chunk into (sub-tile, row, chunk-in-row).
+// A thread's i-th staged chunk occupies the 16-byte LDS slot c = tid + 256 i of the operand's two
+// stacked Tile64 (slot order = LDS address order, which is what a direct-to-LDS load needs: one wave
+// instruction fills 64 consecutive slots).  Returns sub-tile, row and the LOGICAL chunk stored in that
+// slot under the XOR swizzle (slot position p holds chunk p ^ (row & 7)).
 template <typename T> __device__ __forceinline__ void chunk_coord(int tid, int i, int& t, int& row, int& ch) {
     using TL = Tile64<T>;
     const int c = tid + 256 * i;
     t = c / (64 * TL::CH);
     const int w = c % (64 * TL::CH);
     row = w / TL::CH;
-    ch = w % TL::CH;
+    ch = (w % TL::CH) ^ (row & 7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -51,6 +54,7 @@ template <typename T, bool KMAJ> struct PlainSrc {
     const T* p;
     int64_t ld, r0, R, K;
     __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void prefetch(int, int64_t) {}
     __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
         constexpr int EPC = Tile64<T>::EPC;
         if (KMAJ) {
@@ -61,6 +65,19 @@ template <typename T, bool KMAJ> struct PlainSrc {
             const int64_t k = k0 + row, c = r0 + 64 * t + ch * EPC;
             ok = k < K && c < R;
             return p + k * ld + c;
+        }
+    }
+    // always-valid address for a K-step that lies fully inside K: rows / columns beyond R are clamped
+    // (they only feed output rows / columns that are never stored)
+    __device__ __forceinline__ const T* gaddr(int, int t, int row, int ch, int64_t k0) const {
+        constexpr int EPC = Tile64<T>::EPC;
+        if (KMAJ) {
+            const int64_t gr = min(r0 + 64 * t + row, R - 1);
+            return p + gr * ld + k0 + ch * EPC;
+        } else {
+            int64_t c = r0 + 64 * t + ch * EPC;
+            if (c >= R) c = 0;
+            return p + (k0 + row) * ld + c;
         }
     }
 };
@@ -89,13 +106,18 @@ template <typename T> struct ConvRowSrc {
             chunk_coord<T>(tid, i, t, row, ch);
             const int64_t m = r0 + 64 * t + row;
             okr[i] = m < M;
-            base[i] = okr[i] ? (int64_t)pos[m] * g.Cin + ch * Tile64<T>::EPC : 0;
+            base[i] = (int64_t)pos[okr[i] ? m : 0] * g.Cin + ch * Tile64<T>::EPC;
         }
     }
+    __device__ __forceinline__ void prefetch(int, int64_t) {}
     __device__ __forceinline__ const T* addr(int i, int, int, int, int64_t k0, bool& ok) const {
         const int tap = (int)(k0 / g.Cin);
         ok = okr[i];
         return x + base[i] + tap_offset(g, tap) + (k0 % g.Cin);
+    }
+    __device__ __forceinline__ const T* gaddr(int i, int, int, int, int64_t k0) const {
+        const uint32_t k = (uint32_t)k0, tap = k / (uint32_t)g.Cin;   // wave-uniform 32-bit scalar math
+        return x + base[i] + tap_offset(g, (int)tap) + (k - tap * (uint32_t)g.Cin);   // rows beyond M read position 0 (valid)
     }
 };
 
@@ -107,7 +129,16 @@ template <typename T> struct ConvColSrc {
     const int32_t* pos;
     int64_t r0, R, K;         // r0: first (tap, channel) column of this block; R = 45 * Cin; K = M
     ConvGeom g;
+    int32_t posreg[Stage<T>::NCH];      // gather positions of the NEXT K-step, fetched one step ahead
     __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void prefetch(int tid, int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < Stage<T>::NCH; ++i) {
+            int t, row, ch;
+            chunk_coord<T>(tid, i, t, row, ch);
+            posreg[i] = pos[min(k0 + row, K - 1)];
+        }
+    }
     __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
         const int64_t m = k0 + row;
         const int64_t c = r0 + 64 * t + ch * Tile64<T>::EPC;
@@ -115,6 +146,13 @@ template <typename T> struct ConvColSrc {
         const int64_t mm = ok ? m : 0;
         const int tap = (int)(c / g.Cin);
         return x + (int64_t)pos[mm] * g.Cin + tap_offset(g, tap) + (c % g.Cin);
+    }
+    __device__ __forceinline__ const T* gaddr(int i, int t, int, int ch, int64_t) const {
+        // a 64-wide column block never straddles a tap (Cin % 64 == 0): tap and channel base are uniform
+        uint32_t cb = (uint32_t)(r0 + 64 * t);
+        if (cb >= (uint32_t)R) cb = 0;
+        const uint32_t tap = cb / (uint32_t)g.Cin, c0 = cb - tap * (uint32_t)g.Cin;
+        return x + (int64_t)posreg[i] * g.Cin + tap_offset(g, (int)tap) + c0 + ch * Tile64<T>::EPC;
     }
 };
 
@@ -128,6 +166,7 @@ template <typename T> struct ConvWeightColSrc {
     int64_t r0, R, K;         // R = Cin (columns), K = 45 * Cout
     int Cin, Cout;
     __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void prefetch(int, int64_t) {}
     __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
         const int64_t k = k0 + row;
         const int64_t c = r0 + 64 * t + ch * Tile64<T>::EPC;
@@ -136,6 +175,13 @@ template <typename T> struct ConvWeightColSrc {
         const int tapf = 44 - (int)(kk / Cout);
         const int64_t co = kk % Cout;
         return w + (co * 45 + tapf) * (int64_t)Cin + c;
+    }
+    __device__ __forceinline__ const T* gaddr(int, int t, int row, int ch, int64_t k0) const {
+        // Cout % 64 == 0: a K-step stays inside one tap
+        const uint32_t k = (uint32_t)k0, tap = k / (uint32_t)Cout, co0 = k - tap * (uint32_t)Cout;
+        int64_t c = r0 + 64 * t + ch * Tile64<T>::EPC;
+        if (c >= R) c = 0;
+        return w + ((int64_t)(co0 + row) * 45 + (44 - (int)tap)) * (int64_t)Cin + c;
     }
 };
 
@@ -248,8 +294,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
     constexpr int NCH = Stage<T>::NCH;
-    char* ldsA = smem;                       // two Tile64
-    char* ldsB = smem + 2 * TL::BYTES;       // two Tile64
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wr = wave >> 1, wc = wave & 1;
     // consecutive workgroups walk M first so that blocks sharing a B (weight) panel are neighbours
@@ -266,8 +310,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[NCH], rb[NCH];
-    auto fetch = [&](int64_t k0) {
+    // ---- operand staging -------------------------------------------------------------------------
+    // Two LDS stages of (A: 2 x Tile64, B: 2 x Tile64).  Full K-steps go global -> LDS directly
+    // (global_load_lds, 16 B per lane, one wave instruction = 64 consecutive slots; the XOR swizzle
+    // is applied to the per-lane SOURCE address); a ragged last K-step goes through registers with
+    // zero fill.  One barrier per K-step: the loads of step t+1 are in flight during the MFMAs of t.
+    constexpr int STAGE_BYTES = 4 * TL::BYTES;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage_async = [&](int buf, int64_t k0) {
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int t, row, ch;
+            chunk_coord<T>(tid, i, t, row, ch);
+            char* dst = base + (256 * i + 64 * wave_u) * 16;          // wave-uniform; the hardware adds lane * 16
+            __builtin_amdgcn_global_load_lds((glb_ptr)sa.gaddr(i, t, row, ch, k0), (lds_ptr)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)sb.gaddr(i, t, row, ch, k0), (lds_ptr)(dst + 2 * TL::BYTES), 16, 0, 0);
+        }
+    };
+    auto stage_ragged = [&](int buf, int64_t k0) {                     // predicated, zero-filled (K tail)
+        char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int t, row, ch;
@@ -275,18 +339,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
             bool oka, okb;
             const T* pa = sa.addr(i, t, row, ch, k0, oka);
             const T* pb = sb.addr(i, t, row, ch, k0, okb);
-            ra[i] = oka ? *reinterpret_cast<const uint4*>(pa) : make_uint4(0, 0, 0, 0);
-            rb[i] = okb ? *reinterpret_cast<const uint4*>(pb) : make_uint4(0, 0, 0, 0);
+            const uint4 va = oka ? *reinterpret_cast<const uint4*>(pa) : make_uint4(0, 0, 0, 0);
+            const uint4 vb = okb ? *reinterpret_cast<const uint4*>(pb) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(base + (tid + 256 * i) * 16) = va;
+            *reinterpret_cast<uint4*>(base + 2 * TL::BYTES + (tid + 256 * i) * 16) = vb;
         }
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            int t, row, ch;
-            chunk_coord<T>(tid, i, t, row, ch);
-            *reinterpret_cast<uint4*>(ldsA + t * TL::BYTES + TL::chunk_off(row, ch)) = ra[i];
-            *reinterpret_cast<uint4*>(ldsB + t * TL::BYTES + TL::chunk_off(row, ch)) = rb[i];
-        }
+    auto stage = [&](int buf, int64_t kt) {
+        const int64_t k0 = kt * BK;
+        if (k0 + BK <= K) stage_async(buf, k0); else stage_ragged(buf, k0);
     };
 
     const int64_t nk_all = (K + BK - 1) / BK;
@@ -294,13 +355,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
     const int64_t kt_begin = (int64_t)blockIdx.y * per_split;
     const int64_t nk = min(nk_all, kt_begin + per_split);
     if (kt_begin >= nk) return;                       // whole block: nothing to add
-    fetch(kt_begin * BK);
-    commit();
+    sa.prefetch(tid, kt_begin * BK);
+    sb.prefetch(tid, kt_begin * BK);
+    stage(0, kt_begin);
+    if (kt_begin + 1 < nk) { sa.prefetch(tid, (kt_begin + 1) * BK); sb.prefetch(tid, (kt_begin + 1) * BK); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int cur = 0;
     for (int64_t kt = kt_begin; kt < nk; ++kt) {
-        if (kt + 1 < nk) fetch((kt + 1) * BK);
-        const char* tA = ldsA + wr * TL::BYTES;
-        const char* tB = ldsB + wc * TL::BYTES;
+        if (kt + 1 < nk) {
+            stage(cur ^ 1, kt + 1);                   // lands while this step computes
+            if (kt + 2 < nk) { sa.prefetch(tid, (kt + 2) * BK); sb.prefetch(tid, (kt + 2) * BK); }
+        }
+        const char* tA = smem + cur * STAGE_BYTES + wr * TL::BYTES;
+        const char* tB = smem + cur * STAGE_BYTES + 2 * TL::BYTES + wc * TL::BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             Frag<T> fa[4], fb[4];
@@ -315,21 +383,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma(acc[i][j], fb[j], fa[i]);   // rows = n, cols = m
         }
-        __syncthreads();
-        if (kt + 1 < nk) commit();
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next stage has landed ...
+        __syncthreads();                                      // ... for every wave, and this one is free again
+        cur ^= 1;
     }
 
     // epilogue: stage the wave's 64 x 64 fp32 result in LDS (the operand tiles are dead after the last
     // barrier of the loop) and write whole row segments
-    float* stage = reinterpret_cast<float*>(smem) + wave * (64 * STG_LD);
+    float* stg = reinterpret_cast<float*>(smem) + wave * (64 * STG_LD);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)      // acc[i][j]: row (m) = 16 i + li, columns (n) = 16 j + 4 g + r
-            *reinterpret_cast<f32x4*>(stage + (16 * i + li) * STG_LD + 16 * j + 4 * g) = acc[i][j];
+            *reinterpret_cast<f32x4*>(stg + (16 * i + li) * STG_LD + 16 * j + 4 * g) = acc[i][j];
     __syncthreads();
-    RowWriter<TC>::run(stage, ep, m0 + 64 * wr, n0 + 64 * wc, M, N, lane);
+    RowWriter<TC>::run(stg, ep, m0 + 64 * wr, n0 + 64 * wc, M, N, lane);
 }
 
 template <typename T, typename TC, typename SrcA, typename SrcB>
@@ -337,7 +405,7 @@ static int launch_gemm(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, 
                        bool allow_split = false) {
     const int64_t gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
     if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
-    const size_t lds = std::max<size_t>(4 * Tile64<T>::BYTES, STG_BYTES);
+    const size_t lds = std::max<size_t>(2 * 4 * Tile64<T>::BYTES, STG_BYTES);     // two operand stages / epilogue staging
     // split-K (weight gradients: few output tiles, very long contraction): aim at >= 2 tiles per CU while
     // keeping >= 4 K-steps per split; partial sums are added with fp32 atomics into the running C.
     int split = 1;
