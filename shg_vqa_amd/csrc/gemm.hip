@@ -296,8 +296,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
     constexpr int NCH = Stage<T>::NCH;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wr = wave >> 1, wc = wave & 1;
-    // consecutive workgroups walk M first so that blocks sharing a B (weight) panel are neighbours
-    const int64_t bm = blockIdx.x % grid_m, bn = blockIdx.x / grid_m;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
+    // so give each XCD a CONTIGUOUS range of tile ids and walk N fastest inside it: the gn tiles that
+    // re-read one A row-panel (for the convolution: the gathered activations, re-read once per
+    // 128 output channels) run back-to-back on one XCD and hit its L2 instead of the Infinity Cache;
+    // the weight panels are small per K-step and stay L2-resident on every XCD.  Bijective for any grid.
+    const int64_t n_tiles = (int64_t)gridDim.x, gn_t = n_tiles / grid_m;
+    const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
+    const int64_t tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
+    const int64_t bm = tile / gn_t, bn = tile % gn_t;
     const int64_t m0 = bm * BM, n0 = bn * BN;
     sa.r0 = m0;
     sb.r0 = n0;
