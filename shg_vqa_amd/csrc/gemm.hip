@@ -26,19 +26,21 @@
 
 namespace shg {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 
 template <typename T> struct Stage {
-    static constexpr int NCH = (128 * 64 * (int)sizeof(T)) / 16 / 256;   // 16-byte chunks per thread per operand
+    // 16-byte chunks per thread per operand and K-step; both tile configurations keep 128 operand
+    // rows per 256 threads, so the count does not depend on the configuration
+    static constexpr int NCH = (128 * 64 * (int)sizeof(T)) / 16 / 256;
 };
 
-// A thread's i-th staged chunk occupies the 16-byte LDS slot c = tid + 256 i of the operand's two
-// stacked Tile64 (slot order = LDS address order, which is what a direct-to-LDS load needs: one wave
+// A thread's i-th staged chunk occupies the 16-byte LDS slot c = tid + NTHR i of the operand's
+// stacked Tile64s (slot order = LDS address order, which is what a direct-to-LDS load needs: one wave
 // instruction fills 64 consecutive slots).  Returns sub-tile, row and the LOGICAL chunk stored in that
 // slot under the XOR swizzle (slot position p holds chunk p ^ (row & 7)).
-template <typename T> __device__ __forceinline__ void chunk_coord(int tid, int i, int& t, int& row, int& ch) {
+template <typename T, int NTHR> __device__ __forceinline__ void chunk_coord(int tid, int i, int& t, int& row, int& ch) {
     using TL = Tile64<T>;
-    const int c = tid + 256 * i;
+    const int c = tid + NTHR * i;
     t = c / (64 * TL::CH);
     const int w = c % (64 * TL::CH);
     row = w / TL::CH;
@@ -91,7 +93,7 @@ __device__ __forceinline__ int64_t tap_offset(const ConvGeom& g, int tap) {
 }
 
 // A operand of the conv forward: rows = output positions (gathered), K = (tap, channel), K contiguous.
-template <typename T> struct ConvRowSrc {
+template <typename T, int NTHR> struct ConvRowSrc {
     static constexpr bool KMAJOR = true;
     const T* x;
     const int32_t* pos;       // [M] padded-input position index of output position m (tap 0)
@@ -103,7 +105,7 @@ template <typename T> struct ConvRowSrc {
 #pragma unroll
         for (int i = 0; i < Stage<T>::NCH; ++i) {
             int t, row, ch;
-            chunk_coord<T>(tid, i, t, row, ch);
+            chunk_coord<T, NTHR>(tid, i, t, row, ch);
             const int64_t m = r0 + 64 * t + row;
             okr[i] = m < M;
             base[i] = (int64_t)pos[okr[i] ? m : 0] * g.Cin + ch * Tile64<T>::EPC;
@@ -123,7 +125,7 @@ template <typename T> struct ConvRowSrc {
 
 // B operand of the conv weight gradient: rows = reduction index (output positions, gathered),
 // columns = (tap, channel).  Stored with the contraction index strided.
-template <typename T> struct ConvColSrc {
+template <typename T, int NTHR> struct ConvColSrc {
     static constexpr bool KMAJOR = false;
     const T* x;
     const int32_t* pos;
@@ -135,7 +137,7 @@ template <typename T> struct ConvColSrc {
 #pragma unroll
         for (int i = 0; i < Stage<T>::NCH; ++i) {
             int t, row, ch;
-            chunk_coord<T>(tid, i, t, row, ch);
+            chunk_coord<T, NTHR>(tid, i, t, row, ch);
             posreg[i] = pos[min(k0 + row, K - 1)];
         }
     }
@@ -288,14 +290,22 @@ template <> struct RowWriter<float> {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TC, typename SrcA, typename SrcB>
-__global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
-                                                   int grid_m) {
+// TM x TN: operand tiles of 64 rows stacked per workgroup (block tile = 64 TM x 64 TN);
+// WM x WN: wave grid.  Two configurations are instantiated: 2x2 tiles / 2x2 waves (128 x 128, 256
+// threads, 2 workgroups per CU) and, for bf16 problems with enough 256 x 256 tiles to fill the
+// chip, 4x4 tiles / 2x4 waves (each wave 128 x 64; half the operand bytes per flop).
+template <typename T, typename TC, typename SrcA, typename SrcB, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N,
+                                                            int64_t K, int grid_m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
+    constexpr int NTHR = 64 * WM * WN;
     constexpr int NCH = Stage<T>::NCH;
+    static_assert(TM * 64 * TL::CH / NTHR == NCH && TN * 64 * TL::CH / NTHR == NCH, "unsupported tile / thread ratio");
+    constexpr int IM = TM * 64 / WM / 16, JN = TN * 64 / WN / 16;      // 16 x 16 accumulator blocks per wave
+    static_assert(JN == 4 && IM % 4 == 0, "the epilogue stages 64 x 64 pieces");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
     // so give each XCD a CONTIGUOUS range of tile ids and walk N fastest inside it: the gn tiles that
     // re-read one A row-panel (for the convolution: the gathered activations, re-read once per
@@ -305,24 +315,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
     const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
     const int64_t tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
     const int64_t bm = tile / gn_t, bn = tile % gn_t;
-    const int64_t m0 = bm * BM, n0 = bn * BN;
+    const int64_t m0 = bm * (TM * 64), n0 = bn * (TN * 64);
     sa.r0 = m0;
     sb.r0 = n0;
     sa.prepare(tid);
     sb.prepare(tid);
 
-    f32x4 acc[4][4];
+    f32x4 acc[IM][JN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- operand staging -------------------------------------------------------------------------
     // Two LDS stages of (A: 2 x Tile64, B: 2 x Tile64).  Full K-steps go global -> LDS directly
     // (global_load_lds, 16 B per lane, one wave instruction = 64 consecutive slots; the XOR swizzle
     // is applied to the per-lane SOURCE address); a ragged last K-step goes through registers with
     // zero fill.  One barrier per K-step: the loads of step t+1 are in flight during the MFMAs of t.
-    constexpr int STAGE_BYTES = 4 * TL::BYTES;
+    constexpr int STAGE_BYTES = (TM + TN) * TL::BYTES;
+    constexpr int B_OFF = TM * TL::BYTES;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -331,10 +342,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int t, row, ch;
-            chunk_coord<T>(tid, i, t, row, ch);
-            char* dst = base + (256 * i + 64 * wave_u) * 16;          // wave-uniform; the hardware adds lane * 16
+            chunk_coord<T, NTHR>(tid, i, t, row, ch);
+            char* dst = base + (NTHR * i + 64 * wave_u) * 16;         // wave-uniform; the hardware adds lane * 16
             __builtin_amdgcn_global_load_lds((glb_ptr)sa.gaddr(i, t, row, ch, k0), (lds_ptr)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr)sb.gaddr(i, t, row, ch, k0), (lds_ptr)(dst + 2 * TL::BYTES), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)sb.gaddr(i, t, row, ch, k0), (lds_ptr)(dst + B_OFF), 16, 0, 0);
         }
     };
     auto stage_ragged = [&](int buf, int64_t k0) {                     // predicated, zero-filled (K tail)
@@ -342,14 +353,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int t, row, ch;
-            chunk_coord<T>(tid, i, t, row, ch);
+            chunk_coord<T, NTHR>(tid, i, t, row, ch);
             bool oka, okb;
             const T* pa = sa.addr(i, t, row, ch, k0, oka);
             const T* pb = sb.addr(i, t, row, ch, k0, okb);
             const uint4 va = oka ? *reinterpret_cast<const uint4*>(pa) : make_uint4(0, 0, 0, 0);
             const uint4 vb = okb ? *reinterpret_cast<const uint4*>(pb) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(base + (tid + 256 * i) * 16) = va;
-            *reinterpret_cast<uint4*>(base + 2 * TL::BYTES + (tid + 256 * i) * 16) = vb;
+            *reinterpret_cast<uint4*>(base + (tid + NTHR * i) * 16) = va;
+            *reinterpret_cast<uint4*>(base + B_OFF + (tid + NTHR * i) * 16) = vb;
         }
     };
     auto stage = [&](int buf, int64_t kt) {
@@ -374,45 +385,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(SrcA sa, SrcB sb, Epilogue<TC
             stage(cur ^ 1, kt + 1);                   // lands while this step computes
             if (kt + 2 < nk) { sa.prefetch(tid, (kt + 2) * BK); sb.prefetch(tid, (kt + 2) * BK); }
         }
-        const char* tA = smem + cur * STAGE_BYTES + wr * TL::BYTES;
-        const char* tB = smem + cur * STAGE_BYTES + 2 * TL::BYTES + wc * TL::BYTES;
+        // wave (wr, wc) owns rows wr*16*IM .. and columns wc*64 .. of the block tile
+        const char* tA = smem + cur * STAGE_BYTES + (wr * IM / 4) * TL::BYTES;
+        const char* tB = smem + cur * STAGE_BYTES + B_OFF + wc * TL::BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            Frag<T> fa[4], fb[4];
+            Frag<T> fa[IM], fb[JN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[i] = SrcA::KMAJOR ? lds_row_frag<T>(tA, 16 * i + li, 32 * ks, g) : lds_col_frag_nat<T>(tA, 32 * ks, 16 * i, lane);
+            for (int i = 0; i < IM; ++i) {
+                const char* ta = tA + (i / 4) * TL::BYTES;               // 4 blocks of 16 rows per Tile64
+                fa[i] = SrcA::KMAJOR ? lds_row_frag<T>(ta, 16 * (i % 4) + li, 32 * ks, g) : lds_col_frag_nat<T>(ta, 32 * ks, 16 * (i % 4), lane);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < JN; ++j)
                 fb[j] = SrcB::KMAJOR ? lds_row_frag<T>(tB, 16 * j + li, 32 * ks, g) : lds_col_frag_nat<T>(tB, 32 * ks, 16 * j, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma(acc[i][j], fb[j], fa[i]);   // rows = n, cols = m
+                for (int j = 0; j < JN; ++j) mma(acc[i][j], fb[j], fa[i]);   // rows = n, cols = m
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next stage has landed ...
         __syncthreads();                                      // ... for every wave, and this one is free again
         cur ^= 1;
     }
 
-    // epilogue: stage the wave's 64 x 64 fp32 result in LDS (the operand tiles are dead after the last
-    // barrier of the loop) and write whole row segments
+    // epilogue: stage 64 x 64 fp32 pieces of the wave's result in LDS (the operand tiles are dead after
+    // the last barrier of the loop) and write whole row segments
     float* stg = reinterpret_cast<float*>(smem) + wave * (64 * STG_LD);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int h = 0; h < IM / 4; ++h) {
+        if (h) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)      // acc[i][j]: row (m) = 16 i + li, columns (n) = 16 j + 4 g + r
-            *reinterpret_cast<f32x4*>(stg + (16 * i + li) * STG_LD + 16 * j + 4 * g) = acc[i][j];
-    __syncthreads();
-    RowWriter<TC>::run(stg, ep, m0 + 64 * wr, n0 + 64 * wc, M, N, lane);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)      // acc[4h+i][j]: row (m) = 16 i + li, columns (n) = 16 j + 4 g + r
+                *reinterpret_cast<f32x4*>(stg + (16 * i + li) * STG_LD + 16 * j + 4 * g) = acc[4 * h + i][j];
+        __syncthreads();
+        RowWriter<TC>::run(stg, ep, m0 + wr * (16 * IM) + 64 * h, n0 + 64 * wc, M, N, lane);
+    }
 }
 
-template <typename T, typename TC, typename SrcA, typename SrcB>
-static int launch_gemm(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
-                       bool allow_split = false) {
-    const int64_t gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
+template <typename T, typename TC, typename SrcA, typename SrcB, int TM, int TN, int WM, int WN>
+static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
+                      bool allow_split) {
+    constexpr int BMc = TM * 64, BNc = TN * 64, NTHR = 64 * WM * WN;
+    const int64_t gm = (M + BMc - 1) / BMc, gn = (N + BNc - 1) / BNc;
     if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
-    const size_t lds = std::max<size_t>(2 * 4 * Tile64<T>::BYTES, STG_BYTES);     // two operand stages / epilogue staging
+    // two operand stages / one 64 x 64 fp32 epilogue staging piece per wave
+    const size_t lds = std::max<size_t>(2 * (TM + TN) * Tile64<T>::BYTES, (size_t)WM * WN * 64 * STG_LD * 4);
     // split-K (weight gradients: few output tiles, very long contraction): aim at >= 2 tiles per CU while
     // keeping >= 4 K-steps per split; partial sums are added with fp32 atomics into the running C.
     int split = 1;
@@ -421,9 +441,36 @@ static int launch_gemm(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, 
         split = (int)std::min<int64_t>((512 + gm * gn - 1) / (gm * gn), std::max<int64_t>(1, nk / 4));
         if (split > 1) ep.atomic = 1;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, TC, SrcA, SrcB>), dim3((unsigned)(gm * gn), split), dim3(256), lds, st, sa, sb, ep, M, N,
-                       K, (int)gm);
+    auto kern = gemm_kernel<T, TC, SrcA, SrcB, TM, TN, WM, WN>;
+    if (lds > 64 * 1024) {
+        static bool raised = false;          // per instantiation
+        if (!raised) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn), split), dim3(NTHR), lds, st, sa, sb, ep, M, N, K, (int)gm);
     return check_launch(what);
+}
+
+// number of 256 x 256 tiles from which the large configuration is used (one workgroup per CU, 256 CUs)
+constexpr int64_t LARGE_MIN_TILES = 192;
+
+static bool use_large(int dtype_is_bf16, int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    return dtype_is_bf16 && tiles >= LARGE_MIN_TILES && K >= 128;
+}
+
+template <typename T, typename TC, bool AK, bool BK_>
+static int gemm_plain(const T* A, const T* B, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                      hipStream_t st, const char* what) {
+    PlainSrc<T, AK> sa{A, lda, 0, M, K};
+    PlainSrc<T, BK_> sb{B, ldb, 0, N, K};
+    const bool split_ok = !AK && !BK_ && std::is_same<TC, float>::value;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (use_large(1, M, N, K)) return launch_cfg<T, TC, PlainSrc<T, AK>, PlainSrc<T, BK_>, 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, what, split_ok);
+    }
+    return launch_cfg<T, TC, PlainSrc<T, AK>, PlainSrc<T, BK_>, 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, what, split_ok);
 }
 
 template <typename T, typename TC>
@@ -431,14 +478,10 @@ static int gemm_dispatch(const void* a, const void* b, Epilogue<TC> ep, int64_t 
                          int64_t ldb, int a_kmajor, int b_kmajor, hipStream_t st) {
     const T* A = (const T*)a;
     const T* B = (const T*)b;
-    if (a_kmajor && b_kmajor)
-        return launch_gemm<T, TC>(PlainSrc<T, true>{A, lda, 0, M, K}, PlainSrc<T, true>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_nt");
-    if (a_kmajor && !b_kmajor)
-        return launch_gemm<T, TC>(PlainSrc<T, true>{A, lda, 0, M, K}, PlainSrc<T, false>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_nn");
-    if (!a_kmajor && b_kmajor)
-        return launch_gemm<T, TC>(PlainSrc<T, false>{A, lda, 0, M, K}, PlainSrc<T, true>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_tt");
-    return launch_gemm<T, TC>(PlainSrc<T, false>{A, lda, 0, M, K}, PlainSrc<T, false>{B, ldb, 0, N, K}, ep, M, N, K, st, "gemm_tn",
-                              std::is_same<TC, float>::value);
+    if (a_kmajor && b_kmajor) return gemm_plain<T, TC, true, true>(A, B, ep, M, N, K, lda, ldb, st, "gemm_nt");
+    if (a_kmajor && !b_kmajor) return gemm_plain<T, TC, true, false>(A, B, ep, M, N, K, lda, ldb, st, "gemm_nn");
+    if (!a_kmajor && b_kmajor) return gemm_plain<T, TC, false, true>(A, B, ep, M, N, K, lda, ldb, st, "gemm_tt");
+    return gemm_plain<T, TC, false, false>(A, B, ep, M, N, K, lda, ldb, st, "gemm_tn");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -553,15 +596,19 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     ConvGeom g{Cin, H + 2, W + 2};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SHG_F32) {
-        ConvRowSrc<float> sa{(const float*)x, pos_in, 0, M, g};
+        ConvRowSrc<float, 256> sa{(const float*)x, pos_in, 0, M, g};
         PlainSrc<float, true> sb{(const float*)w, K, 0, N, K};
         Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (float*)y_pre, 0};
-        return launch_gemm<float, float>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
+        return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);
     }
-    ConvRowSrc<bf16_t> sa{(const bf16_t*)x, pos_in, 0, M, g};
     PlainSrc<bf16_t, true> sb{(const bf16_t*)w, K, 0, N, K};
     Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre, 0};
-    return launch_gemm<bf16_t, bf16_t>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
+    if (use_large(1, M, N, K)) {
+        ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
+        return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);
+    }
+    ConvRowSrc<bf16_t, 256> sa{(const bf16_t*)x, pos_in, 0, M, g};
+    return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);
 }
 
 extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
@@ -577,12 +624,16 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
     Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1, nullptr, 0};
     if (dtype == SHG_F32) {
         PlainSrc<float, false> sa{(const float*)dy, Cout, 0, Cout, Mo};
-        ConvColSrc<float> sb{(const float*)x, pos_in, 0, Ncols, Mo, g};
-        return launch_gemm<float, float>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+        ConvColSrc<float, 256> sb{(const float*)x, pos_in, 0, Ncols, Mo, g};
+        return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
     }
     PlainSrc<bf16_t, false> sa{(const bf16_t*)dy, Cout, 0, Cout, Mo};
-    ConvColSrc<bf16_t> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
-    return launch_gemm<bf16_t, float>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+    if (use_large(1, Cout, Ncols, Mo)) {
+        ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
+        return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
+    }
+    ConvColSrc<bf16_t, 256> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
+    return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
 }
 
 extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
@@ -598,15 +649,19 @@ extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void*
     ConvGeom g{Cout, H + 2, W + 2};
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SHG_F32) {
-        ConvRowSrc<float> sa{(const float*)dy_padded, pos_in, 0, M, g};
+        ConvRowSrc<float, 256> sa{(const float*)dy_padded, pos_in, 0, M, g};
         ConvWeightColSrc<float> sb{(const float*)w, 0, N, K, Cin, Cout};
         Epilogue<float> ep{(float*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
-        return launch_gemm<float, float>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
+        return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad", false);
     }
-    ConvRowSrc<bf16_t> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
     ConvWeightColSrc<bf16_t> sb{(const bf16_t*)w, 0, N, K, Cin, Cout};
     Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
-    return launch_gemm<bf16_t, bf16_t>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
+    if (use_large(1, M, N, K)) {
+        ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
+        return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad", false);
+    }
+    ConvRowSrc<bf16_t, 256> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
+    return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad", false);
 }
 
 extern "C" int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int T, int H, int W, void* stream) {

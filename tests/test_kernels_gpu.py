@@ -464,3 +464,26 @@ def test_gemm_split_k_accumulates_into_running_sum(K):
     out = c0.clone().to(DEV)
     K.gemm(dy.to(DEV), x.to(DEV), out, None, False, False, accumulate=True)
     assert torch.allclose(out.cpu(), ref, rtol=2e-3, atol=0.5), (out.cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize("akm,bkm", [(True, True), (True, False), (False, True), (False, False)])
+def test_gemm_large_tile_configuration(K, akm, bkm):
+    """Shapes with >= 192 tiles of 256 x 256 take the 4x4-tile / 8-wave kernel (bf16 only)."""
+    _gemm_case(K, torch.bfloat16, akm, bkm, 4104, 3080, 832, False, torch.bfloat16, with_bias=True)
+    _gemm_case(K, torch.bfloat16, akm, bkm, 4096, 3072, 776, False, torch.float32, with_bias=False)
+    _gemm_case(K, torch.bfloat16, akm, bkm, 3592, 3592, 520, True, torch.float32, with_bias=False)
+
+
+def test_gemm_large_tile_integer_layout(K):
+    M, N, Kd = 3584, 3584, 128
+    a = (torch.arange(M * Kd).view(M, Kd) % 7 - 3).float()
+    b = (torch.arange(N * Kd).view(N, Kd) % 5 - 2).float()
+    b[3, 5] = 9
+    ref = a @ b.t()
+    for akm in (True, False):
+        for bkm in (True, False):
+            aa = (a if akm else a.t().contiguous()).to(torch.bfloat16).to(DEV)
+            bb = (b if bkm else b.t().contiguous()).to(torch.bfloat16).to(DEV)
+            out = torch.empty(M, N, device=DEV)
+            K.gemm(aa, bb, out, None, akm, bkm)
+            assert torch.equal(out.cpu(), ref), (akm, bkm)
