@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exec", dest="exec_mode", default="auto", choices=["auto", "graph", "eager"],
+                    help="graph: replay the step from a captured hipGraph; eager: launch every kernel from Python; "
+                         "auto = graph on one GPU, eager under torch.distributed")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,15 +123,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    mode = a.exec_mode if a.exec_mode != "auto" else ("graph" if world == 1 else "eager")
+    if mode == "graph":
+        trainer.capture(batches[0])
+        log("step captured into a hipGraph")
+        step_fn = trainer.train_step_graphed
+    else:
+        step_fn = trainer.train_step
     for i in range(a.warmup):
-        trainer.train_step(batches[i % len(batches)])
+        step_fn(batches[i % len(batches)])
         torch.cuda.synchronize()
         log("warm-up step %d done" % i)
     sync()
     E.kernel_events = []
     t0 = time.perf_counter()
     for i in range(a.steps):
-        trainer.train_step(batches[i % len(batches)])
+        step_fn(batches[i % len(batches)])
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -154,7 +164,7 @@ def main():
             "config": {"workload": "agqaHGQA.py --taskHGQA --LossHGPerFrame full SHG-VQA model, llayers/xlayers/rlayers 5/2/5, "
                                    "dlayers 5, slow_r50-shaped feats (B,2048,16,7,7), per-GPU batch %d, random --fromScratch init "
                                    "(BASELINE.json configs[2]; configs[4] at 8 GPUs)" % B,
-                       "global_batch": world * B, "parallelism": "dp%d" % world},
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "execution": mode},
             "step_mfma_frac": round(qa / world * TRAIN_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"kernel": "gemm_kernel<bf16, ConvRowSrc> (shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -173,10 +173,14 @@ class AGQA:
         return dict(total=bce.sum() * (self.world.bce_scale() if self.world is not None else 1.0), bce=bce.sum().detach(),
                     logit=logit, hg_logit=logit)
 
-    def train_step(self, b):
-        """agqaHGQA.py:262-392 for one device batch."""
+    def _conv1_params(self):
+        vf = self.model.lxrt_encoder.model.bert.encoder.visn_fc
+        return vf.conv[1].weight, vf.conv[1].bias
+
+    def _step_body(self, b):
+        """zero_grad -> forward -> losses -> backward -> (gradient exchange) -> clip -> BertAdam.
+        Everything here only enqueues device work (no host synchronisation), so it can be captured."""
         E = engine()
-        self.model.train()
         E.begin_step()
         self.optim.zero_grad(set_to_none=True)
         if self.world is not None:
@@ -188,6 +192,61 @@ class AGQA:
         out["grad_norm"] = clip_grad_norm_(self.model.parameters(), 5.0)
         self.optim.step()
         return out
+
+    def train_step(self, b):
+        """agqaHGQA.py:262-392 for one device batch (eager launches)."""
+        self.model.train()
+        engine().conv1_cache = None
+        return self._step_body(b)
+
+    # ------------------------------------------------------------------ hipGraph execution
+    def capture(self, example):
+        """Captures one optimiser step into a hipGraph (torch.cuda.CUDAGraph).  The ~1 600 launches of a
+        step are then replayed by the GPU front-end without any Python / launch overhead; per-step
+        state that changes (dropout step counter, schedule step, batch) lives in device memory.
+        The conv1 forward (the dominant kernel) stays OUTSIDE the graph: it is launched eagerly into
+        persistent buffers right before the replay, which keeps it individually timeable."""
+        from . import ops as _ops
+        E = engine()
+        self.model.train()
+        self._static = {k: v.clone() for k, v in example.items() if torch.is_tensor(v)}
+        w1, b1 = self._conv1_params() if not self.args.task_q else (None, None)
+        self._conv1_bufs = None
+        if w1 is not None:
+            self._conv1_bufs = _ops.conv1_forward(self._static["feat"], w1, b1, None)
+
+        def body():
+            if w1 is not None:
+                E.conv1_cache = self._conv1_bufs
+            return self._step_body(self._static)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up: caches (masks, gather tables), DDP write counts
+                if w1 is not None:
+                    _ops.conv1_forward(self._static["feat"], w1, b1, self._conv1_bufs)
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_out = body()
+        E.conv1_cache = None
+        return self
+
+    def train_step_graphed(self, b):
+        """Copies the batch into the captured buffers, runs conv1 eagerly, replays the rest of the step."""
+        from . import ops as _ops
+        st = self._static
+        for k, v in b.items():
+            if torch.is_tensor(v) and k in st:
+                st[k].copy_(v, non_blocking=True)
+        if self._conv1_bufs is not None:
+            w1, b1 = self._conv1_params()
+            _ops.conv1_forward(st["feat"], w1, b1, self._conv1_bufs)
+        self._graph.replay()
+        return self._graph_out
 
     # ------------------------------------------------------------------ loops (agqaHGQA.py:233-455, :459-630)
     def train(self, train_tuple=None, eval_tuple=None):

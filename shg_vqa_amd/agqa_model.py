@@ -139,7 +139,15 @@ class AGQAModel(nn.Module):
         E = engine()
         if compute_dtype is not None:
             E.compute_dtype = compute_dtype
-        E.adopt(self, self.active_parameter_names())
+        groups = []
+        for name, mod in self.named_modules():
+            if isinstance(mod, M.BertAttention):
+                groups += mod.fusion_groups(name + ".")
+                mod._fz = None
+        # shared modules are registered under several names: keep the groups whose names are canonical
+        canon = {n for n, _ in self.named_parameters()}
+        groups = [g for g in groups if all(n in canon for n in g)]
+        E.adopt(self, self.active_parameter_names(), groups)
         return self
 
     def train(self, mode=True):

@@ -20,6 +20,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mma.h"
@@ -433,12 +434,15 @@ static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, i
     if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
     // two operand stages / one 64 x 64 fp32 epilogue staging piece per wave
     const size_t lds = std::max<size_t>(2 * (TM + TN) * Tile64<T>::BYTES, (size_t)WM * WN * 64 * STG_LD * 4);
-    // split-K (weight gradients: few output tiles, very long contraction): aim at >= 2 tiles per CU while
-    // keeping >= 4 K-steps per split; partial sums are added with fp32 atomics into the running C.
+    // split-K (weight gradients: few output tiles, very long contraction): aim at ~1.5 workgroups per CU while
+    // keeping >= 4 K-steps per split (measured best of 128/256/384/512/768 on the step's shapes: more
+    // splits are throttled by the ~1.3 TB/s chip-wide fp32 atomic rate); partial sums go into the running C
+    // with fp32 atomics in 256-byte row segments.
     int split = 1;
     const int64_t nk = (K + BK - 1) / BK;
     if (allow_split && ep.accumulate && gm * gn < 384) {
-        split = (int)std::min<int64_t>((512 + gm * gn - 1) / (gm * gn), std::max<int64_t>(1, nk / 4));
+        static const int64_t target = []() { const char* e = getenv("SHG_SPLITK_TARGET"); return e ? (int64_t)atoi(e) : (int64_t)384; }();
+        split = (int)std::min<int64_t>((target + gm * gn - 1) / (gm * gn), std::max<int64_t>(1, nk / 4));
         if (split > 1) ep.atomic = 1;
     }
     auto kern = gemm_kernel<T, TC, SrcA, SrcB, TM, TN, WM, WN>;
@@ -454,7 +458,7 @@ static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, i
 }
 
 // number of 256 x 256 tiles from which the large configuration is used (one workgroup per CU, 256 CUs)
-constexpr int64_t LARGE_MIN_TILES = 192;
+constexpr int64_t LARGE_MIN_TILES = 128;
 
 static bool use_large(int dtype_is_bf16, int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);

@@ -70,10 +70,17 @@ class Engine:
         return self._stream_id
 
     # ------------------------------------------------------------------ arenas
-    def adopt(self, model, active_names):
+    def adopt(self, model, active_names, groups=()):
         """Moves every parameter of `model` into the arenas.  active_names: set of parameter names
-        (as in named_parameters()) that receive gradients for the configured task."""
+        (as in named_parameters()) that receive gradients for the configured task.  groups: lists of
+        parameter names to lay out back-to-back (e.g. query/key/value weights -> one [2304,768] operand)."""
         named = list(model.named_parameters())
+        order = {n: i for i, (n, _) in enumerate(named)}
+        for grp in groups:                                   # pull a group's members right behind its first one
+            base = order[grp[0]]
+            for j, n in enumerate(grp[1:], 1):
+                order[n] = base + j * 1e-3
+        named.sort(key=lambda np_: order[np_[0]])
         act = [(n, p) for n, p in named if n in active_names]
         ina = [(n, p) for n, p in named if n not in active_names]
         missing = set(active_names) - {n for n, _ in named}

@@ -304,7 +304,7 @@ def conv_workspace(B, T, H, W, device):
     return ws
 
 
-def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False):
+def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None):
     """x_cl [B,T,H+2,W+2,Cin] (zero border); w_cl [Cout,5,3,3,Cin]; -> y [B,T-4,H,W,Cout]
     (or written into the interior of a zero-bordered [B,T-4,H+2,W+2,Cout] buffer when pad_out)."""
     _dev(x_cl, w_cl, bias, out)
@@ -319,7 +319,10 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, wan
         shape = (B, T - 4, Hp, Wp, cout) if pad_out else (B, T - 4, H, W, cout)
         out = (torch.zeros if pad_out else torch.empty)(shape, dtype=x_cl.dtype, device=x_cl.device)
     _need(out.is_contiguous() and out.dtype == x_cl.dtype, "out must be contiguous and of x's dtype")
-    pre = torch.empty((B, T - 4, H, W, cout), dtype=x_cl.dtype, device=x_cl.device) if want_pre else None
+    pre = None
+    if want_pre:
+        pre = pre_out if pre_out is not None else torch.empty((B, T - 4, H, W, cout), dtype=x_cl.dtype, device=x_cl.device)
+        _need(pre.is_contiguous() and pre.dtype == x_cl.dtype and pre.numel() == B * (T - 4) * H * W * cout, "bad pre_out")
     _lib.call("shg_conv3d_k533_fwd", x_cl.data_ptr(), w_cl.data_ptr(), _p(bias), out.data_ptr(), _dt(x_cl), B, T, H, W, cin,
               cout, act, 1 if pad_out else 0, _p(pre), ws.data_ptr(), _stream())
     return (out, pre) if want_pre else out
@@ -355,12 +358,13 @@ def conv3d_k533_dgrad(dy_padded, w_cl):
     return dx
 
 
-def ncdhw_to_padded_cl(x, dtype):
-    """[B,C,T,H,W] fp32 -> [B,T,H+2,W+2,C] `dtype`, zero border."""
-    _dev(x)
+def ncdhw_to_padded_cl(x, dtype, out=None):
+    """[B,C,T,H,W] fp32 -> [B,T,H+2,W+2,C] `dtype`, zero border (`out`: a zero-bordered buffer to reuse)."""
+    _dev(x, out)
     _need(x.dim() == 5 and x.dtype == torch.float32 and x.is_contiguous(), "x must be contiguous fp32 NCDHW")
     B, C, T, H, W = x.shape
-    y = torch.zeros((B, T, H + 2, W + 2, C), dtype=dtype, device=x.device)
+    y = out if out is not None else torch.zeros((B, T, H + 2, W + 2, C), dtype=dtype, device=x.device)
+    _need(tuple(y.shape) == (B, T, H + 2, W + 2, C) and y.dtype == dtype and y.is_contiguous(), "bad out buffer")
     _lib.call("shg_ncdhw_to_padded_cl", x.data_ptr(), y.data_ptr(), _dt(y), B, C, T, H, W, _stream())
     return y
 

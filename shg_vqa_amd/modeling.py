@@ -136,13 +136,29 @@ class BertAttention(nn.Module):
         self.value = nn.Linear(ctx_dim, self.all_head_size)
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
+    def fusion_groups(self, prefix):
+        """Parameter groups Engine.adopt lays out back-to-back so that Q/K/V are one GEMM operand."""
+        return [[prefix + n + ".weight" for n in ("query", "key", "value")],
+                [prefix + n + ".bias" for n in ("query", "key", "value")]]
+
+    def _fused(self):
+        if getattr(self, "_fz", None) is None:
+            P = ops.ParamConcat
+            self._fz = (P([self.query.weight, self.key.weight, self.value.weight]),
+                        P([self.query.bias, self.key.bias, self.value.bias]),
+                        P([self.key.weight, self.value.weight]), P([self.key.bias, self.value.bias]))
+        return self._fz
+
     def forward(self, hidden_states, context, attention_mask=None):
-        q = ops.linear(hidden_states, self.query.weight, self.query.bias)
-        k = ops.linear(context, self.key.weight, self.key.bias)
-        v = ops.linear(context, self.value.weight, self.value.bias)
         kind, mask = key_mask_2d(attention_mask)
-        o = ops.attention(q, k, v, self.num_attention_heads, kind, mask, 1.0 / math.sqrt(self.attention_head_size),
-                          self.dropout.p)
+        scale = 1.0 / math.sqrt(self.attention_head_size)
+        w_qkv, b_qkv, w_kv, b_kv = self._fused()
+        if context is hidden_states:
+            o = ops.self_attention_qkv(hidden_states, w_qkv, b_qkv, self.num_attention_heads, kind, mask, scale,
+                                       self.dropout.p)
+        else:
+            o = ops.cross_attention_qkv(hidden_states, context, self.query.weight, self.query.bias, w_kv, b_kv,
+                                        self.num_attention_heads, kind, mask, scale, self.dropout.p)
         return o, None
 
 

@@ -1,0 +1,43 @@
+"""Micro-benchmark of shg_gemm on the shapes of one HGQA step (run on the GPU box).
+Prints time and TFLOP/s per shape and layout; used to tune tile configurations."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from shg_vqa_amd import kernels as K
+
+dev = "cuda"
+shapes = [(12576, 768, 768), (12576, 2304, 768), (12576, 3072, 768), (12576, 768, 3072), (12576, 1536, 768), (4096, 768, 768),
+          (4096, 1536, 768), (4096, 2048, 768), (4096, 768, 2048), (1536, 768, 768), (1280, 768, 768), (1280, 3072, 768),
+          (5664, 768, 768), (5664, 3072, 768)]
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+for (M, N, Kd) in shapes:
+    x = torch.randn(M, Kd, device=dev).bfloat16()
+    w = torch.randn(N, Kd, device=dev).bfloat16()
+    dy = torch.randn(M, N, device=dev).bfloat16()
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    dx = torch.empty(M, Kd, device=dev, dtype=torch.bfloat16)
+    dw = torch.zeros(N, Kd, device=dev)
+    fl = 2.0 * M * N * Kd
+    t_f = bench(lambda: K.gemm(x, w, y, None, True, True))
+    t_d = bench(lambda: K.gemm(dy, w, dx, None, True, False))
+    t_w = bench(lambda: K.gemm(dy, x, dw, None, False, False, accumulate=True))
+    t_ref = bench(lambda: torch.matmul(x, w.t())) if not os.environ.get("WGRAD_ONLY") else 0.0
+    if os.environ.get("WGRAD_ONLY"):
+        print("M=%6d N=%5d K=%5d wgrad %7.1f us %6.0f TF" % (M, N, Kd, t_w, fl / t_w / 1e6), flush=True)
+        continue
+    print("M=%6d N=%5d K=%5d  fwd %7.1f us %6.0f TF | dgrad %7.1f us %6.0f TF | wgrad %7.1f us %6.0f TF | torch.mm fwd %7.1f us %6.0f TF"
+          % (M, N, Kd, t_f, fl / t_f / 1e6, t_d, fl / t_d / 1e6, t_w, fl / t_w / 1e6, t_ref, fl / t_ref / 1e6), flush=True)
