@@ -9,8 +9,8 @@
 namespace shg {
 
 constexpr int LN_MAX_CHUNKS = 8;        // 16-byte chunks per lane held in registers
-constexpr int ROWS_PER_PARTIAL = 32;    // rows folded into one partial row of the column sums
-constexpr int MAX_PARTIALS = 2048;
+constexpr int ROWS_PER_PARTIAL = 8;   // rows folded into one partial row of the column sums
+constexpr int MAX_PARTIALS = 4096;
 
 __host__ inline int colsum_partials(int64_t rows) {
     int64_t n = (rows + ROWS_PER_PARTIAL - 1) / ROWS_PER_PARTIAL;
@@ -300,22 +300,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     partial[(int64_t)blockIdx.y * cols + c] = acc;
 }
 
-// second stage of the column reductions: block = 64 columns x 16 partial-row groups
+// second stage of the column reductions: block = 64 columns x 16 partial-row groups; the partial rows
+// are cut into gridDim.y slices whose sums are combined with fp32 atomics (<= 8 adders per address)
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int n_partials, int cols,
-                                                             float* __restrict__ out, int accumulate) {
+                                                             float* __restrict__ out) {
     __shared__ float sh[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
+    const int per = (n_partials + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(n_partials, p0 + per);
     float s = 0.f;
     if (c < cols)
-        for (int p = ty; p < n_partials; p += 16) s += partial[(int64_t)p * cols + c];
+        for (int p = p0 + ty; p < p1; p += 16) s += partial[(int64_t)p * cols + c];
     sh[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && c < cols) {
+    if (ty == 0 && c < cols && p0 < p1) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sh[k][tx];
-        out[c] = accumulate ? out[c] + t : t;
+        atomicAdd(out + c, t);
     }
 }
 
@@ -390,8 +393,10 @@ extern "C" int shg_colsum_partial(const void* x, int dtype, int64_t rows, int co
 
 extern "C" int shg_colsum_finish(const float* partial, int n_partials, int cols, float* out, int accumulate, void* stream) {
     if (!partial || !out || n_partials < 1 || cols < 1) return fail_arg("colsum_finish: bad argument");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial,
-                       n_partials, cols, out, accumulate);
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), st);
+    const int slices = n_partials >= 256 ? 8 : (n_partials >= 64 ? 4 : 1);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 63) / 64, slices), dim3(1024), 0, st, partial, n_partials, cols, out);
     return check_launch("colsum_finish");
 }
 
