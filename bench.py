@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="use the gradient reducer / RCCL path even with one rank (testing)")
     ap.add_argument("--exec", dest="exec_mode", default="auto", choices=["auto", "graph", "eager"],
                     help="graph: replay the step from a captured hipGraph; eager: launch every kernel from Python; "
                          "auto = graph on one GPU, eager under torch.distributed")
@@ -94,7 +95,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or a.force_ddp:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from shg_vqa_amd.agqa_hgqa import AGQA, DataTuple, SyntheticAGQA
@@ -111,7 +114,9 @@ def main():
     model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=args)
     model.to_engine(cdt)
     E = engine()
-    reducer = GradReducer(E.grad_arena) if world > 1 else None
+    reducer = GradReducer(E.grad_arena) if (world > 1 or a.force_ddp) else None
+    if reducer is not None and a.force_ddp:
+        reducer.world = 2 if world == 1 else reducer.world      # take the collective code path (a 1-rank all-reduce is the identity)
     trainer = AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=1), [None] * 1000, None), model=model, t_total=10000,
                    world=reducer)
     log("model in HBM arenas (%d params, %d with gradients); building batches" % (E.n_total, E.n_active))
@@ -155,6 +160,13 @@ def main():
     conv1_flop = 2.0 * (B * 12 * 49) * 768 * (45 * 2048)
     achieved = conv1_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_conv1_latest.json")
+    if os.path.exists(pmc) and B == 32 and a.dtype == "bf16":
+        with open(pmc) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
+        traffic_src = "profiles/pmc_conv1_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 x2 fetch correction)"
+
     if rank == 0:
         qa = world * B * a.steps / elapsed
         line = {
@@ -168,7 +180,7 @@ def main():
             "step_mfma_frac": round(qa / world * TRAIN_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"kernel": "gemm_kernel<bf16, ConvRowSrc> (shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(k_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs)},
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -176,7 +188,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             log("cpu baseline done")
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
