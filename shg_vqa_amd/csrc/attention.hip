@@ -6,7 +6,8 @@
 // The running max / sum / rescale of the online softmax are therefore lane-local (two xor-shuffles
 // join the four 16-lane groups), P never goes through LDS, and V^T is read from the row-major V
 // tile with the transposing LDS read.  K and V tiles (64 keys x 64) are staged in LDS once per
-// workgroup (4 waves = 64 queries) with 16-byte coalesced loads and an XOR swizzle.
+// workgroup (4 waves = 64 queries), double-buffered: the next tile streams global -> LDS directly
+// (global_load_lds, XOR swizzle on the source address) while the current one feeds the MFMAs.
 // The [B,H,Sq,Sk] score tensor of the reference (modeling_capsbert.py:394-418) is never formed.
 //
 // Backward recomputes P from the saved log-sum-exp:
@@ -45,16 +46,17 @@ template <typename T, int MASK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restrict__ o, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
-    char* ldsK = smem;
-    char* ldsV = smem + TL::BYTES;
+    // two stages of (K tile, V tile): the next key tile streams into LDS while this one is consumed
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
     const int qidx = blockIdx.x * 64 + wave * 16 + li;
     const int qrow = min(qidx, P.Sq - 1);
     const T* qptr = (const T*)P.q + (int64_t)b * P.q_bs + (int64_t)qrow * P.q_ss + h * 64;
-    const Frag<T> qf0 = glb_row_frag(qptr, 0, g), qf1 = glb_row_frag(qptr, 32, g);
     const T* kbase = (const T*)P.k + (int64_t)b * P.k_bs + h * 64;
     const T* vbase = (const T*)P.v + (int64_t)b * P.v_bs + h * 64;
+    load_tile64_async<T>(smem, kbase, P.k_ss, min(64, P.Sk), tid);
+    load_tile64_async<T>(smem + TL::BYTES, vbase, P.v_ss, min(64, P.Sk), tid);
+    const Frag<T> qf0 = glb_row_frag(qptr, 0, g), qf1 = glb_row_frag(qptr, 32, g);
     const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
     const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)P.Sk;
 
@@ -62,13 +64,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc_o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
 
     for (int kb = 0; kb < P.Sk; kb += 64) {
-        __syncthreads();
-        const int valid = min(64, P.Sk - kb);
-        load_tile64<T>(ldsK, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
-        load_tile64<T>(ldsV, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
-        __syncthreads();
+        const char* ldsK = smem + cur * 2 * TL::BYTES;
+        const char* ldsV = ldsK + TL::BYTES;
+        if (kb + 64 < P.Sk) {
+            char* nxt = smem + (cur ^ 1) * 2 * TL::BYTES;
+            const int valid = min(64, P.Sk - kb - 64);
+            load_tile64_async<T>(nxt, kbase + (int64_t)(kb + 64) * P.k_ss, P.k_ss, valid, tid);
+            load_tile64_async<T>(nxt + TL::BYTES, vbase + (int64_t)(kb + 64) * P.v_ss, P.v_ss, valid, tid);
+        }
 
         f32x4 s[4];
 #pragma unroll
@@ -119,6 +127,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
 #pragma unroll
             for (int d = 0; d < 4; ++d) mma(acc_o[d], lds_col_frag<T>(ldsV, 32 * sx, 16 * d, lane), pf);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
     }
     if (qidx < P.Sq) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -140,14 +151,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
                                                           T* __restrict__ dq, int64_t dq_bs, int64_t dq_ss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
-    char* ldsK = smem;
-    char* ldsV = smem + TL::BYTES;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
     const int qidx = blockIdx.x * 64 + wave * 16 + li;
     const int qrow = min(qidx, P.Sq - 1);
     const T* qptr = (const T*)P.q + (int64_t)b * P.q_bs + (int64_t)qrow * P.q_ss + h * 64;
     const int64_t orow = ((int64_t)b * P.Sq + qrow) * (P.H * 64) + h * 64;
+    const T* kbase = (const T*)P.k + (int64_t)b * P.k_bs + h * 64;
+    const T* vbase = (const T*)P.v + (int64_t)b * P.v_bs + h * 64;
     const Frag<T> qf0 = glb_row_frag(qptr, 0, g), qf1 = glb_row_frag(qptr, 32, g);
     const Frag<T> df0 = glb_row_frag(d_o + orow, 0, g), df1 = glb_row_frag(d_o + orow, 32, g);
     const int64_t stat = ((int64_t)b * P.H + h) * P.Sq + qrow;
@@ -161,21 +172,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
         if (g == 0 && qidx < P.Sq) delta[stat] = dl;
     }
     const float lse_q = lse[stat];
-    const T* kbase = (const T*)P.k + (int64_t)b * P.k_bs + h * 64;
-    const T* vbase = (const T*)P.v + (int64_t)b * P.v_bs + h * 64;
     const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
     const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)P.Sk;
 
     f32x4 acc[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (all ordinary global loads above are consumed before the first direct-to-LDS load is issued)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load_tile64_async<T>(smem, kbase, P.k_ss, min(64, P.Sk), tid);
+    load_tile64_async<T>(smem + TL::BYTES, vbase, P.v_ss, min(64, P.Sk), tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
 
     for (int kb = 0; kb < P.Sk; kb += 64) {
-        __syncthreads();
-        const int valid = min(64, P.Sk - kb);
-        load_tile64<T>(ldsK, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
-        load_tile64<T>(ldsV, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
-        __syncthreads();
+        const char* ldsK = smem + cur * 2 * TL::BYTES;
+        const char* ldsV = ldsK + TL::BYTES;
+        if (kb + 64 < P.Sk) {
+            char* nxt = smem + (cur ^ 1) * 2 * TL::BYTES;
+            const int valid = min(64, P.Sk - kb - 64);
+            load_tile64_async<T>(nxt, kbase + (int64_t)(kb + 64) * P.k_ss, P.k_ss, valid, tid);
+            load_tile64_async<T>(nxt + TL::BYTES, vbase + (int64_t)(kb + 64) * P.v_ss, P.v_ss, valid, tid);
+        }
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -204,6 +223,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
 #pragma unroll
             for (int d = 0; d < 4; ++d) mma(acc[d], lds_col_frag<T>(ldsK, 32 * sx, 16 * d, lane), dsf);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
     }
     if (qidx < P.Sq) {
         T* out = dq + (int64_t)b * dq_bs + (int64_t)qidx * dq_ss + h * 64;
@@ -224,10 +246,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                                                            T* __restrict__ dv, int64_t dv_bs, int64_t dv_ss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
-    char* ldsQ = smem;
-    char* ldsD = smem + TL::BYTES;
-    float* ldsLse = reinterpret_cast<float*>(smem + 2 * TL::BYTES);
-    float* ldsDelta = ldsLse + 64;
+    // two stages of (Q tile, dO tile, lse[64], delta[64])
+    constexpr int STG = 2 * TL::BYTES + 512;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kidx = blockIdx.x * 64 + wave * 16 + li;
@@ -242,22 +262,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
     const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
     const uint64_t drop_bh = (uint64_t)(b * P.H + h) * P.Sq;
     const float kmask = (MASK == SHG_MASK_KEY) ? P.mask[(int64_t)b * P.Sk + krow] : 0.f;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    auto stage = [&](int buf, int qb) {
+        char* base = smem + buf * STG;
+        const int valid = min(64, P.Sq - qb);
+        load_tile64_async<T>(base, qbase + (int64_t)qb * P.q_ss, P.q_ss, valid, tid);
+        load_tile64_async<T>(base + TL::BYTES, dbase + (int64_t)qb * (P.H * 64), P.H * 64, valid, tid);
+        // per-query statistics: 64 floats each, one 4-byte direct-to-LDS load per lane (waves 0 and 1)
+        const int qq = min(qb + lane, P.Sq - 1);
+        if (wave_u == 0) __builtin_amdgcn_global_load_lds((glb_ptr)(lse + stat0 + qq), (lds_ptr)(base + 2 * TL::BYTES), 4, 0, 0);
+        if (wave_u == 1) __builtin_amdgcn_global_load_lds((glb_ptr)(delta + stat0 + qq), (lds_ptr)(base + 2 * TL::BYTES + 256), 4, 0, 0);
+    };
 
     f32x4 acc_k[4], acc_v[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) { acc_k[d] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_v[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the register loads above are complete
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
 
     for (int qb = 0; qb < P.Sq; qb += 64) {
-        __syncthreads();
-        const int valid = min(64, P.Sq - qb);
-        load_tile64<T>(ldsQ, qbase + (int64_t)qb * P.q_ss, P.q_ss, valid, tid);
-        load_tile64<T>(ldsD, dbase + (int64_t)qb * (P.H * 64), P.H * 64, valid, tid);
-        if (tid < 64) {
-            const int qq = min(qb + tid, P.Sq - 1);
-            ldsLse[tid] = lse[stat0 + qq];
-            ldsDelta[tid] = delta[stat0 + qq];
-        }
-        __syncthreads();
+        const char* ldsQ = smem + cur * STG;
+        const char* ldsD = ldsQ + TL::BYTES;
+        const float* ldsLse = reinterpret_cast<const float*>(ldsQ + 2 * TL::BYTES);
+        const float* ldsDelta = ldsLse + 64;
+        if (qb + 64 < P.Sq) stage(cur ^ 1, qb + 64);
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -299,6 +332,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                 mma(acc_k[d], lds_col_frag<T>(ldsQ, 32 * sx, 16 * d, lane), dsf);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
     }
     if (kidx < P.Sk) {
         T* ok = dk + (int64_t)b * dk_bs + (int64_t)kidx * dk_ss + h * 64;
@@ -348,8 +384,8 @@ extern "C" int shg_attention_fwd(const void* q, const void* k, const void* v, vo
     if (!o || !lse) return fail_arg("attention_fwd: null output");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((Sq + 63) / 64, H, B), block(256);
-    if (dtype == SHG_F32) ATTN_DISPATCH(attn_fwd_kernel, float, 2 * Tile64<float>::BYTES, P, (float*)o, lse);
-    else ATTN_DISPATCH(attn_fwd_kernel, bf16_t, 2 * Tile64<bf16_t>::BYTES, P, (bf16_t*)o, lse);
+    if (dtype == SHG_F32) ATTN_DISPATCH(attn_fwd_kernel, float, 4 * Tile64<float>::BYTES, P, (float*)o, lse);
+    else ATTN_DISPATCH(attn_fwd_kernel, bf16_t, 4 * Tile64<bf16_t>::BYTES, P, (bf16_t*)o, lse);
     return check_launch("attention_fwd");
 }
 
@@ -369,16 +405,16 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
     {
         dim3 grid((Sq + 63) / 64, H, B);
         if (dtype == SHG_F32)
-            ATTN_DISPATCH(attn_bwd_dq_kernel, float, 2 * Tile64<float>::BYTES, P, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, dq_bstride, dq_sstride);
+            ATTN_DISPATCH(attn_bwd_dq_kernel, float, 4 * Tile64<float>::BYTES, P, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, dq_bstride, dq_sstride);
         else
-            ATTN_DISPATCH(attn_bwd_dq_kernel, bf16_t, 2 * Tile64<bf16_t>::BYTES, P, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, dq_bstride, dq_sstride);
+            ATTN_DISPATCH(attn_bwd_dq_kernel, bf16_t, 4 * Tile64<bf16_t>::BYTES, P, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, dq_bstride, dq_sstride);
     }
     {
         dim3 grid((Sk + 63) / 64, H, B);
         if (dtype == SHG_F32)
-            ATTN_DISPATCH(attn_bwd_dkv_kernel, float, 2 * Tile64<float>::BYTES + 512, P, (const float*)d_o, lse, delta, (float*)dk, dk_bstride, dk_sstride, (float*)dv, dv_bstride, dv_sstride);
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, float, 2 * (2 * Tile64<float>::BYTES + 512), P, (const float*)d_o, lse, delta, (float*)dk, dk_bstride, dk_sstride, (float*)dv, dv_bstride, dv_sstride);
         else
-            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 2 * Tile64<bf16_t>::BYTES + 512, P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 2 * (2 * Tile64<bf16_t>::BYTES + 512), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
     }
     return check_launch("attention_bwd");
 }

@@ -54,6 +54,26 @@ __device__ __forceinline__ void load_tile64(char* lds, const T* src, int64_t row
     }
 }
 
+// Asynchronous variant: global -> LDS directly (global_load_lds, 16 B per lane; one wave instruction
+// fills 64 consecutive 16-byte slots, the swizzle is applied to the per-lane SOURCE address).  Rows
+// beyond rows_valid re-read the last valid row (finite garbage the caller masks out).  The data is only
+// visible after the issuing waves' s_waitcnt vmcnt(0) and a workgroup barrier.
+template <typename T>
+__device__ __forceinline__ void load_tile64_async(char* lds, const T* src, int64_t row_stride, int rows_valid, int tid) {
+    using TL = Tile64<T>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 64 * TL::CH / 256; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / TL::CH, ch = (c % TL::CH) ^ (row & 7);
+        const int rsrc = min(row, rows_valid - 1);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src + (int64_t)rsrc * row_stride + ch * TL::EPC),
+                                         (lds_ptr)(lds + (256 * i + 64 * wave_u) * 16), 16, 0, 0);
+    }
+}
+
 // slot (g, j) <-> element k0 + 8g + j of `row` (contraction index contiguous in memory)
 __device__ __forceinline__ Frag<bf16_t> lds_row_frag(const char* lds, int row, int k0, int g, bf16_t*) {
     Frag<bf16_t> f;
