@@ -288,6 +288,33 @@ class AGQA:
                 quesid2ans[qid] = l
         return quesid2ans
 
+    @torch.no_grad()
+    def test(self, eval_tuple, dump=None):
+        """agqaHGQA.py:632-798: target-free inference (segment ids only, no matcher / losses); returns and
+        optionally dumps {question id: answer index}."""
+        import json
+        dset, loader, evaluator = eval_tuple
+        self.model.eval()
+        quesid2ans = {}
+        for batch in loader:
+            b = batch_to_device(batch, self.device)
+            engine().begin_step()
+            B = b["input_ids"].shape[0]
+            if self.args.task_hgqa:
+                rel_seg = frame_segment_ids(B, self.num_situations, self.num_rel, self.device)
+                act_seg = frame_segment_ids(B, self.num_situations, self.num_act, self.device)
+                _, _, _, hg_logit, _ = self.model(b["feat"], b["pos"], input_ids=b["input_ids"], input_masks=b["input_mask"],
+                                                  segment_ids=b["segment_ids"], rel_segment_ids=rel_seg,
+                                                  act_segment_ids=act_seg, hg_mask=b.get("hg_mask"))
+            else:
+                hg_logit = self.forward_losses(b)["logit"]
+            for qid, l in zip(batch["ques_id"].tolist(), hg_logit.argmax(1).cpu().tolist()):
+                quesid2ans[qid] = l
+        if dump is not None:
+            with open(dump, "w") as f:
+                json.dump({str(k): int(v) for k, v in quesid2ans.items()}, f)
+        return quesid2ans
+
     def evaluate(self, eval_tuple, dump=None):
         return eval_tuple.evaluator.evaluateOverall(self.predict(eval_tuple, dump))
 

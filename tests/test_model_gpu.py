@@ -197,3 +197,97 @@ def test_state_dict_roundtrip_keeps_reference_keys(tmp_path, golden_dir):
     a = sd2["lxrt_encoder.model.bert.encoder.x_layers.0.visual_attention.att.query.weight"]
     c = sd2["lxrt_encoder.model.bert.encoder.cross_attn_layer.cross.visual_attention.att.query.weight"]
     assert a.data_ptr() == c.data_ptr()
+
+
+def _build_task(task_flag, extra=(), n_ans=171):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from shg_vqa_amd.agqa_hgqa import AGQA, SyntheticAGQA, DataTuple
+    from shg_vqa_amd.agqa_model import AGQAModel
+    from shg_vqa_amd.engine import reset_engine
+    from shg_vqa_amd.param import parse_args
+    reset_engine(compute_dtype=torch.float32)
+    args = parse_args(["--noCaps", task_flag, "--fromScratch", "--computeDtype", "fp32", "--lr", "1e-4"] + list(extra))
+    model = AGQAModel(n_ans, args=args)
+    model.to_engine(torch.float32)
+    _load_det_weights(model)
+    return AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=4), [None] * 10, None), model=model, t_total=100)
+
+
+def test_question_only_model_matches_reference_golden(golden_dir):
+    """BASELINE.json configs[0]: agqaQ.py --taskQ, llayers=2 (forward logits + BCE loss vs the reference)."""
+    from oracle import shg_ref
+    g = np.load(os.path.join(golden_dir, "agqa_q_b4.npz"))
+    tr = _build_task("--taskQ", ["--llayers", "2"])
+    cfg = shg_ref.Cfg(llayers=2, task="q")
+    batch = shg_ref.synthetic_batch(int(g["batch_size"]), cfg, seed=int(g["batch_seed"]), with_feat=False)
+    b = {k: v.to(DEV) for k, v in batch.items() if torch.is_tensor(v)}
+    tr.model.eval()
+    from shg_vqa_amd.engine import engine
+    engine().begin_step()
+    out = tr.forward_losses(b)
+    assert _rel_err(out["logit"], g["logit"]) < 1e-3
+    assert abs(float(out["total"]) - float(g["loss"])) < 1e-3 * float(g["loss"])
+    assert set(n for n, _ in tr.model.named_parameters()) == set(str(x) for x in g["param_names"])
+
+
+def test_vqa_task_train_step_matches_oracle():
+    """BASELINE.json configs[1]: agqaVQA.py --taskVQA 5/2/5 (video + question, BCE on the LXRT answer logit):
+    here the x-layers and their pooler DO receive gradients."""
+    from oracle import shg_ref
+    tr = _build_task("--taskVQA")
+    cfg = shg_ref.Cfg(task="vqa")
+    p = shg_ref.det_params(cfg, requires_grad=True)
+    batch = shg_ref.synthetic_batch(2, cfg, seed=31)
+    out_o, losses_o, grads_o, norm_o = shg_ref.train_step(p, cfg, batch, {}, lr=1e-4, step=3, t_total=100)
+    b = _device_batch(batch)
+    from shg_vqa_amd.engine import engine
+    from shg_vqa_amd.optimization import clip_grad_norm_
+    engine().step_state.fill_(3)
+    engine().begin_step()
+    tr.optim.zero_grad()
+    engine().training = False
+    out = tr.forward_losses(b)
+    out["total"].backward()
+    norm = clip_grad_norm_(tr.model.parameters(), 5.0)
+    tr.optim.step()
+    assert _rel_err(out["logit"], out_o["logit"].detach()) < 1e-3
+    assert abs(float(out["total"]) - float(losses_o["total"])) < 1e-3 * float(losses_o["total"])
+    assert abs(norm.item() - float(norm_o)) < 5e-3 * float(norm_o)
+    params = dict(tr.model.named_parameters())
+    assert set(grads_o) == tr.model.active_parameter_names()
+    for n in ("lxrt_encoder.model.bert.encoder.cross_attn_layer.cross.visn_output.dense.weight",
+              "lxrt_encoder.model.bert.pooler_dict.cross.dense2.weight", "logit_fc.0.bias"):
+        assert torch.allclose(params[n].detach().float().cpu(), p[n].detach(), rtol=1e-3, atol=2e-6), n
+
+
+def test_training_loop_entry_points_run_and_learn(tmp_path):
+    """get_tuple / AGQA.train / predict / test / evaluate / save / load on a tiny synthetic split: the loss of a
+    repeated batch must go down and a reloaded checkpoint must reproduce the predictions."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from shg_vqa_amd.agqa_hgqa import AGQA, batch_to_device, get_tuple
+    from shg_vqa_amd.engine import engine, reset_engine
+    from shg_vqa_amd.param import hgqa_args
+    reset_engine(compute_dtype=torch.bfloat16)
+    args = hgqa_args(batch_size=4, epochs=1, lr=2e-4, output=str(tmp_path), log_freq=1000)
+    torch.manual_seed(1)
+    train = get_tuple("train", 4, shuffle=False, drop_last=True, n=8)
+    valid = get_tuple("valid", 4, n=8)
+    agqa = AGQA(args, train_tuple=train, valid_tuple=valid, t_total=40)
+    engine().step_state.fill_(10)                      # past the lr = 0 first step of the schedule
+    b = batch_to_device(next(iter(train.loader)), agqa.device)
+    losses = [float(agqa.train_step(b)["total"]) for _ in range(6)]
+    assert losses[-1] < losses[0], losses
+    agqa.train(train, valid)                           # one epoch through the loop (saves CURRENT/BEST/LAST)
+    assert os.path.exists(os.path.join(str(tmp_path), "LAST.pth"))
+    p1 = agqa.predict(valid)
+    t1 = agqa.test(valid, dump=os.path.join(str(tmp_path), "pred.json"))
+    assert p1 == t1 and len(p1) == 8
+    with torch.no_grad():
+        for prm in agqa.model.parameters():
+            prm.data.mul_(0.5)
+    engine().refresh_shadows()
+    agqa.load(os.path.join(str(tmp_path), "LAST"))
+    assert agqa.predict(valid) == p1
+    assert 0.0 <= agqa.evaluate(valid) <= 1.0

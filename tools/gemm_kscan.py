@@ -1,0 +1,15 @@
+"""Fixed cost vs per-K-step cost of shg_gemm on a small grid (GPU-paced through a hipGraph)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from shg_vqa_amd import kernels as K
+from gemm_shapes import bench  # noqa
+
+for (M, N) in ((1280, 768), (4096, 768), (12576, 768)):
+    for Kd in (64, 128, 256, 512, 768, 1536, 3072):
+        x = torch.randn(M, Kd, device="cuda").bfloat16()
+        w = torch.randn(N, Kd, device="cuda").bfloat16()
+        y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        t = bench(lambda: K.gemm(x, w, y, None, True, True))
+        t2 = bench(lambda: torch.matmul(x, w.t()))
+        print("M=%6d N=%5d K=%5d  %7.1f us   torch %7.1f us" % (M, N, Kd, t, t2), flush=True)
