@@ -38,14 +38,15 @@ template <typename T> struct Stage {
 // A thread's i-th staged chunk occupies the 16-byte LDS slot c = tid + NTHR i of the operand's
 // stacked Tile64s (slot order = LDS address order, which is what a direct-to-LDS load needs: one wave
 // instruction fills 64 consecutive slots).  Returns sub-tile, row and the LOGICAL chunk stored in that
-// slot under the XOR swizzle (slot position p holds chunk p ^ (row & 7)).
-template <typename T, int NTHR> __device__ __forceinline__ void chunk_coord(int tid, int i, int& t, int& row, int& ch) {
+// slot under the operand's XOR swizzle (contraction-contiguous tiles: p ^ (row & 7); contraction-strided
+// tiles, read with the transposing LDS read: p ^ swz_ks(row)).
+template <typename T, int NTHR, bool KMAJ> __device__ __forceinline__ void chunk_coord(int tid, int i, int& t, int& row, int& ch) {
     using TL = Tile64<T>;
     const int c = tid + NTHR * i;
     t = c / (64 * TL::CH);
     const int w = c % (64 * TL::CH);
     row = w / TL::CH;
-    ch = (w % TL::CH) ^ (row & 7);
+    ch = (w % TL::CH) ^ TL::template swz<KMAJ>(row);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -106,7 +107,7 @@ template <typename T, int NTHR> struct ConvRowSrc {
 #pragma unroll
         for (int i = 0; i < Stage<T>::NCH; ++i) {
             int t, row, ch;
-            chunk_coord<T, NTHR>(tid, i, t, row, ch);
+            chunk_coord<T, NTHR, true>(tid, i, t, row, ch);
             const int64_t m = r0 + 64 * t + row;
             okr[i] = m < M;
             base[i] = (int64_t)pos[okr[i] ? m : 0] * g.Cin + ch * Tile64<T>::EPC;
@@ -138,7 +139,7 @@ template <typename T, int NTHR> struct ConvColSrc {
 #pragma unroll
         for (int i = 0; i < Stage<T>::NCH; ++i) {
             int t, row, ch;
-            chunk_coord<T, NTHR>(tid, i, t, row, ch);
+            chunk_coord<T, NTHR, false>(tid, i, t, row, ch);
             posreg[i] = pos[min(k0 + row, K - 1)];
         }
     }
@@ -342,22 +343,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int t, row, ch;
-            chunk_coord<T, NTHR>(tid, i, t, row, ch);
+            int t, row, cha, chb;
+            chunk_coord<T, NTHR, SrcA::KMAJOR>(tid, i, t, row, cha);
+            chunk_coord<T, NTHR, SrcB::KMAJOR>(tid, i, t, row, chb);
             char* dst = base + (NTHR * i + 64 * wave_u) * 16;         // wave-uniform; the hardware adds lane * 16
-            __builtin_amdgcn_global_load_lds((glb_ptr)sa.gaddr(i, t, row, ch, k0), (lds_ptr)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr)sb.gaddr(i, t, row, ch, k0), (lds_ptr)(dst + B_OFF), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)sa.gaddr(i, t, row, cha, k0), (lds_ptr)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)sb.gaddr(i, t, row, chb, k0), (lds_ptr)(dst + B_OFF), 16, 0, 0);
         }
     };
     auto stage_ragged = [&](int buf, int64_t k0) {                     // predicated, zero-filled (K tail)
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int t, row, ch;
-            chunk_coord<T, NTHR>(tid, i, t, row, ch);
+            int t, row, cha, chb;
+            chunk_coord<T, NTHR, SrcA::KMAJOR>(tid, i, t, row, cha);
+            chunk_coord<T, NTHR, SrcB::KMAJOR>(tid, i, t, row, chb);
             bool oka, okb;
-            const T* pa = sa.addr(i, t, row, ch, k0, oka);
-            const T* pb = sb.addr(i, t, row, ch, k0, okb);
+            const T* pa = sa.addr(i, t, row, cha, k0, oka);
+            const T* pb = sb.addr(i, t, row, chb, k0, okb);
             const uint4 va = oka ? *reinterpret_cast<const uint4*>(pa) : make_uint4(0, 0, 0, 0);
             const uint4 vb = okb ? *reinterpret_cast<const uint4*>(pb) : make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(base + (tid + NTHR * i) * 16) = va;
@@ -442,7 +445,8 @@ static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, i
     const int64_t nk = (K + BK - 1) / BK;
     if (allow_split && ep.accumulate && gm * gn < 384) {
         static const int64_t target = []() { const char* e = getenv("SHG_SPLITK_TARGET"); return e ? (int64_t)atoi(e) : (int64_t)384; }();
-        split = (int)std::min<int64_t>((target + gm * gn - 1) / (gm * gn), std::max<int64_t>(1, nk / 4));
+        static const int64_t min_steps = []() { const char* e = getenv("SHG_SPLITK_MIN_STEPS"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
+        split = (int)std::min<int64_t>((target + gm * gn - 1) / (gm * gn), std::max<int64_t>(1, nk / min_steps));
         if (split > 1) ep.atomic = 1;
     }
     auto kern = gemm_kernel<T, TC, SrcA, SrcB, TM, TN, WM, WN>;

@@ -38,6 +38,18 @@ template <typename T> struct Tile64 {
     __device__ __forceinline__ static int elem_off(int row, int col) {
         return chunk_off(row, col / EPC) + (col % EPC) * (int)sizeof(T);
     }
+    // Swizzle for tiles whose ROWS are the contraction index and that are only read with the
+    // transposing LDS read (GEMM operands stored "contraction strided").  One ds_read_b64_tr_b16 of a
+    // 32-lane half touches rows {8g+q : g in 2 groups, q = 0..3} x two adjacent 16-byte chunks; rows of the
+    // same parity share a 128-byte half of the 256-byte bank window, so the mask must differ in chunk bits
+    // 1..2 between rows r, r+2 (same group) and r, r+8 (the other group): mask = ((r>>1)&1)*2 + ((r>>3)&1)*4.
+    // With (row & 7) instead, rows r and r+8 collide (2-way conflict on every transposed read).
+    __device__ __forceinline__ static int swz_ks(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
+    __device__ __forceinline__ static int chunk_off_ks(int row, int chunk) { return row * ROWB + ((chunk ^ swz_ks(row)) << 4); }
+    __device__ __forceinline__ static int elem_off_ks(int row, int col) {
+        return chunk_off_ks(row, col / EPC) + (col % EPC) * (int)sizeof(T);
+    }
+    template <bool KMAJ> __device__ __forceinline__ static int swz(int row) { return KMAJ ? (row & 7) : swz_ks(row); }
 };
 
 // Copies a 64 x 64 tile (rows beyond rows_valid are zero-filled) from global memory into a swizzled
@@ -159,13 +171,14 @@ template <typename T> __device__ __forceinline__ Frag<T> lds_col_frag(const char
 
 // Natural-order variant: slot (g, j) <-> tile[kb + 8g + j][col0 + li], i.e. the same k a row fragment
 // of the other operand holds in that slot (GEMM operands stored with the contraction index strided).
+// These tiles use the transposed-read swizzle (Tile64::swz_ks).
 __device__ __forceinline__ Frag<bf16_t> lds_col_frag_nat(const char* lds, int kb, int col0, int lane, bf16_t*) {
     typedef __attribute__((address_space(3))) s16x4* lds_v4;
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int r0 = kb + 8 * g + q, r1 = r0 + 4;
     const int col = col0 + 4 * p;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + Tile64<bf16_t>::elem_off(r0, col)));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + Tile64<bf16_t>::elem_off(r1, col)));
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + Tile64<bf16_t>::elem_off_ks(r0, col)));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + Tile64<bf16_t>::elem_off_ks(r1, col)));
     union { s16x4 s[2]; bf16x8 v; } u;
     u.s[0] = a;
     u.s[1] = b;
@@ -178,7 +191,7 @@ __device__ __forceinline__ Frag<float> lds_col_frag_nat(const char* lds, int kb,
     Frag<float> f;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        f.v[j] = *reinterpret_cast<const float*>(lds + Tile64<float>::elem_off(kb + 8 * g + j, col));
+        f.v[j] = *reinterpret_cast<const float*>(lds + Tile64<float>::elem_off_ks(kb + 8 * g + j, col));
     return f;
 }
 template <typename T> __device__ __forceinline__ Frag<T> lds_col_frag_nat(const char* lds, int kb, int col0, int lane) {
