@@ -84,8 +84,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="use the gradient reducer / RCCL path even with one rank (testing)")
     ap.add_argument("--exec", dest="exec_mode", default="auto", choices=["auto", "graph", "eager"],
-                    help="graph: replay the step from a captured hipGraph; eager: launch every kernel from Python; "
-                         "auto = graph on one GPU, eager under torch.distributed")
+                    help="eager: launch every kernel from Python (weight gradients overlap the input-gradient chain on a "
+                         "side stream); graph: replay the step from a captured hipGraph (no launch overhead, but the "
+                         "runtime serialises the side-stream branch: measured slower); auto = eager")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +129,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    mode = a.exec_mode if a.exec_mode != "auto" else ("graph" if world == 1 else "eager")
+    mode = a.exec_mode if a.exec_mode != "auto" else "eager"
     if mode == "graph":
         trainer.capture(batches[0])
         log("step captured into a hipGraph")

@@ -47,6 +47,13 @@ class GradReducer:
         self.comm_stream = torch.cuda.Stream() if self.use_streams else None
         self.launch_order = []
 
+    def extra_streams(self):
+        try:
+            from .engine import engine
+            return engine().side_streams()
+        except Exception:
+            return []
+
     # ------------------------------------------------------------------ hooks
     def begin_step(self):
         self.counts = [0] * len(self.bounds)
@@ -75,6 +82,8 @@ class GradReducer:
             return
         if self.use_streams:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for s_ in self.extra_streams():               # weight gradients are written on a side stream
+                self.comm_stream.wait_stream(s_)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM)
         else:

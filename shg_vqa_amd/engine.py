@@ -50,6 +50,8 @@ class Engine:
         self.training = False            # dropout on/off; set by AGQAModel.train()/eval()
         self.grad_ready_hook = None      # set by ddp: called with (offset, numel) after a gradient write
         self.model = None
+        self.overlap_wgrad = True         # weight gradients on a side stream (ops._WgradStream)
+        self._wgrad_stream = None
         self.kernel_events = None        # bench.py: list collecting (start, end) events of the dominant kernel
         self.pending_clip = None
 
@@ -133,6 +135,23 @@ class Engine:
     def operand(self, p):
         """The tensor a matrix-core kernel should read for parameter p (storage layout)."""
         return p._shg_shadow if self.compute_dtype == torch.bfloat16 else p._shg_store
+
+    # ------------------------------------------------------------------ side stream for weight gradients
+    def wgrad_stream(self):
+        if not self.overlap_wgrad or self.device.type != "cuda":
+            return None
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+        return self._wgrad_stream
+
+    def side_streams(self):
+        return [s for s in (self._wgrad_stream,) if s is not None]
+
+    def join_side_streams(self):
+        """Makes the current stream wait for all weight-gradient work issued so far."""
+        cur = torch.cuda.current_stream()
+        for s in self.side_streams():
+            cur.wait_stream(s)
 
     def zero_grad(self):
         if self.grad_arena is not None:

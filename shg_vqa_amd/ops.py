@@ -50,6 +50,53 @@ def _padded_rows(dy2):
     return buf[:, :n]
 
 
+class _WgradStream:
+    """Context that runs weight-gradient work on the engine's side stream.
+
+    dW = dY^T X is off the critical path of backward (nothing downstream in backward reads it), while
+    the input-gradient chain is a sequence of small, latency-bound launches.  Issuing the weight
+    gradients on a second stream lets the GPU overlap them with that chain (as branches of the captured
+    hipGraph, or as concurrent eager launches).  Ordering: the side stream first waits for everything the
+    main stream has enqueued so far (dY and X are complete there); consumers of the gradient arena
+    (norm / optimiser / all-reduce) wait for the side stream (Engine.join_side_streams)."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.E = engine()
+        self.side = self.E.wgrad_stream()
+
+    def __enter__(self):
+        if self.side is None:
+            return self
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.side is None:
+            return False
+        self.ctx.__exit__(*a)
+        for t in self.tensors:                 # keep the allocator from recycling them under the side stream
+            if t is not None:
+                t.record_stream(self.side)
+        return False
+
+
+def _wgrad(dy2, x2, weight, bias):
+    """Accumulates dW += dy^T x and db += colsum(dy) into the gradient arena (on the side stream)."""
+    E = engine()
+    if weight._shg_grad is None:
+        return
+    with _WgradStream(dy2, x2):
+        K.gemm(dy2, x2, weight._shg_grad, None, False, False, accumulate=True)
+        if bias is not None:
+            K.colsum(dy2, bias._shg_grad.view(-1), True)
+    E.grad_written(weight)
+    if bias is not None:
+        E.grad_written(bias)
+
+
 # ------------------------------------------------------------------------------------------------
 class _Linear(torch.autograd.Function):
     """y = x W^T (+ b in the GEMM epilogue).  nn.Linear of mc:373-375, :427, :466, :481."""
@@ -76,17 +123,12 @@ class _Linear(torch.autograd.Function):
         weight, bias = ctx.weight, ctx.bias
         w = E.operand(weight)
         dy2 = _padded_rows(_rows2d(dy))
+        _wgrad(dy2, x2, weight, bias)          # first: it only needs dy, and runs beside the dgrad chain
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(x2.shape, dtype=x2.dtype, device=x2.device)
             K.gemm(dy2, w, dx, None, True, False)
             dx = dx.view(ctx.xshape)
-        if weight._shg_grad is not None:
-            K.gemm(dy2, x2, weight._shg_grad, None, False, False, accumulate=True)
-            E.grad_written(weight)
-            if bias is not None:
-                K.colsum(dy2, bias._shg_grad.view(-1), True)
-                E.grad_written(bias)
         return dx, None, None, None
 
 
@@ -308,7 +350,8 @@ class _VisualConvTokens(torch.autograd.Function):
         # conv2: GELU', bias grad, weight grad, input grad
         d2, part = K.bias_act_bwd(pre2, None, d_tok, ACT_GELU, want_dbias=True)
         _acc_vec(part, b2)
-        K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+        with _WgradStream(y1p, d2):
+            K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
         E.grad_written(w2)
         # input gradient of conv2 = the forward gather over dy padded by (4 in T, 1 in H/W); the kernel reads
         # the weight flipped / transposed in place
@@ -316,7 +359,8 @@ class _VisualConvTokens(torch.autograd.Function):
         d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2))
         d1, part1 = K.bias_act_bwd(pre1, None, d_y1, ACT_GELU, want_dbias=True)
         _acc_vec(part1, b1)
-        K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
+        with _WgradStream(x_cl, d1):
+            K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
         E.grad_written(w1)
         return None, None, None, None, None, None, None, None, None
 
@@ -513,18 +557,6 @@ def _anchor(p):
     return p.base if isinstance(p, (ParamSlice, ParamConcat)) else p
 
 
-def _wgrad(dy2, x2, weight, bias):
-    """Accumulates dW += dy^T x and db += colsum(dy) into the gradient arena."""
-    E = engine()
-    if weight._shg_grad is None:
-        return
-    K.gemm(dy2, x2, weight._shg_grad, None, False, False, accumulate=True)
-    E.grad_written(weight)
-    if bias is not None:
-        K.colsum(dy2, bias._shg_grad.view(-1), True)
-        E.grad_written(bias)
-
-
 class _SelfAttnQKV(torch.autograd.Function):
     """Fused-projection self-attention: ONE GEMM (N = 3*768) for Q/K/V, attention on strided views of its
     output, and in backward the attention kernels write dQ/dK/dV straight into one [.., 3*768] buffer
@@ -556,12 +588,12 @@ class _SelfAttnQKV(torch.autograd.Function):
         d3 = dqkv.view(B, S, 3 * H)
         K.attention_bwd(q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:], o, d_o.contiguous(), lse,
                         d3[:, :, :H], d3[:, :, H:2 * H], d3[:, :, 2 * H:], heads, mask_kind, mask, scale, p, seed, sid)
+        _wgrad(dqkv, x2, w_qkv, b_qkv)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
             K.gemm(dqkv, E.operand(w_qkv), dx, None, True, False)
             dx = dx.view(B, S, H)
-        _wgrad(dqkv, x2, w_qkv, b_qkv)
         return dx, None, None, None, None, None, None, None, None
 
 
@@ -599,6 +631,8 @@ class _CrossAttnQKV(torch.autograd.Function):
         dkv3 = dkv.view(B, Sk, 2 * H)
         K.attention_bwd(q.view(B, Sq, H), kv3[:, :, :H], kv3[:, :, H:], o, d_o.contiguous(), lse, dq.view(B, Sq, H),
                         dkv3[:, :, :H], dkv3[:, :, H:], heads, mask_kind, mask, scale, p, seed, sid)
+        _wgrad(dq, h2, w_q, b_q)
+        _wgrad(dkv, c2, w_kv, b_kv)
         dh = dc = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(h2)
@@ -608,8 +642,6 @@ class _CrossAttnQKV(torch.autograd.Function):
             dc = torch.empty_like(c2)
             K.gemm(dkv, E.operand(w_kv), dc, None, True, False)
             dc = dc.view(B, Sk, H)
-        _wgrad(dq, h2, w_q, b_q)
-        _wgrad(dkv, c2, w_kv, b_kv)
         return dh, dc, None, None, None, None, None, None, None, None, None, None
 
 

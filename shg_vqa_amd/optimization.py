@@ -19,6 +19,7 @@ def clip_grad_norm_(parameters, max_norm):
     the global L2 norm of the gradient arena on the device and hands the clip to the next
     BertAdam.step(), which folds the scaling into its update kernel.  Returns the norm (fp32 [1], device)."""
     E = engine()
+    E.join_side_streams()                       # weight gradients may still be in flight on the side stream
     E.pending_clip = (K.grad_norm(E.grad_arena), float(max_norm))
     return E.pending_clip[0]
 
@@ -48,6 +49,7 @@ class BertAdam(torch.optim.Optimizer):
         if E.param_arena is None:
             raise RuntimeError("BertAdam needs the parameters to live in the engine arenas (Engine.adopt)")
         g = self.param_groups[0]
+        E.join_side_streams()
         norm, max_norm = getattr(E, "pending_clip", None) or (None, 0.0)
         E.pending_clip = None
         n = E.n_active
