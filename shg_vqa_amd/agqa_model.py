@@ -54,14 +54,22 @@ class HGDecoder(nn.Module):
     def forward(self, memory, rel_segment_ids, act_segment_ids):
         B = memory.shape[0]
         dev = memory.device
-        outs = []
-        for emb, dec, head, seg, per in ((self.relation_query_embed, self.rel_decoder, self.class_embed, rel_segment_ids, self.num_rel),
-                                         (self.action_query_embed, self.action_decoder, self.action_embed, act_segment_ids, self.num_act)):
+
+        def decode(emb, dec, head, seg, per):
             qpos = emb(seg)
             mask = rel_target_mask_device(self.num_situations, per, dev)
             out = dec.forward_bf(torch.zeros_like(qpos), memory, qpos, mask)
-            outs.append((out, M.mlp_head(head, out)))
-        (rel_out, rel_preds), (act_out, act_preds) = outs
+            return out, M.mlp_head(head, out)
+
+        # the two decoders only share `memory`: the action decoder runs on a side stream beside the
+        # relation decoder (both are chains of small launches that leave most of the GPU idle)
+        branch = ops.Branch(1, memory, act_segment_ids)
+        with branch:
+            act_out, act_preds = decode(self.action_query_embed, self.action_decoder, self.action_embed, act_segment_ids,
+                                        self.num_act)
+        rel_out, rel_preds = decode(self.relation_query_embed, self.rel_decoder, self.class_embed, rel_segment_ids,
+                                    self.num_rel)
+        branch.join(act_out, act_preds)
         T = self.num_situations
         hg_in = torch.cat([act_out.view(B, T, -1, self.hid_dim), rel_out.view(B, T, -1, self.hid_dim)], dim=2)
         return rel_preds, act_preds, hg_in.view(B, -1, self.hid_dim)

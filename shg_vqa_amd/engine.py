@@ -52,6 +52,8 @@ class Engine:
         self.model = None
         self.overlap_wgrad = True         # weight gradients on a side stream (ops._WgradStream)
         self._wgrad_stream = None
+        self.overlap_branches = True      # independent sub-graphs (action decoder, language layers) on side streams
+        self._aux_streams = {}
         self.kernel_events = None        # bench.py: list collecting (start, end) events of the dominant kernel
         self.pending_clip = None
 
@@ -144,8 +146,16 @@ class Engine:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         return self._wgrad_stream
 
+    def aux_stream(self, i):
+        """Side stream for an independent branch of the model (None: run it inline)."""
+        if not self.overlap_branches or self.device.type != "cuda":
+            return None
+        if i not in self._aux_streams:
+            self._aux_streams[i] = torch.cuda.Stream(device=self.device)
+        return self._aux_streams[i]
+
     def side_streams(self):
-        return [s for s in (self._wgrad_stream,) if s is not None]
+        return [s for s in (self._wgrad_stream,) if s is not None] + list(self._aux_streams.values())
 
     def join_side_streams(self):
         """Makes the current stream wait for all weight-gradient work issued so far."""

@@ -454,13 +454,17 @@ class NoCapsEncoder(nn.Module):
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask=None,
                 output_all_attention_masks=False):
-        visn_feats, _ = self.visn_fc(visn_feats)
-        for layer in self.layer:
-            lang_feats, _ = layer(lang_feats, lang_attention_mask)
+        # the language layers (tiny launches) run on a side stream beside the conv stack + relation layers
+        branch = ops.Branch(2, lang_feats, lang_attention_mask)
+        with branch:
+            for layer in self.layer:
+                lang_feats, _ = layer(lang_feats, lang_attention_mask)
         lang_out = lang_feats
+        visn_feats, _ = self.visn_fc(visn_feats)
         for layer in self.r_layers:
             visn_feats, _ = layer(visn_feats, visn_attention_mask)
         visn_out = visn_feats
+        branch.join(lang_feats)
         for layer in self.x_layers:
             lang_feats, visn_feats, _ = layer(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         return lang_feats, visn_feats, ([], [], [], [], [], (lang_out, lang_attention_mask, visn_out, visn_attention_mask))

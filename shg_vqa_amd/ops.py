@@ -50,6 +50,41 @@ def _padded_rows(dy2):
     return buf[:, :n]
 
 
+class Branch:
+    """Runs an independent sub-graph of the model on a side stream (with-block), e.g. the action decoder
+    beside the relation decoder.  Autograd replays each backward node on the stream of its forward, so
+    the backward of the branch overlaps as well.  `inputs`: tensors produced on the main stream that the
+    branch reads; call `.publish(*outs)` on the tensors the main stream consumes after `.join()`."""
+
+    def __init__(self, index, *inputs):
+        self.side = engine().aux_stream(index)
+        self.main = torch.cuda.current_stream() if self.side is not None else None
+        self.inputs = inputs
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.main)
+            for t in self.inputs:
+                if t is not None:
+                    t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+    def join(self, *outs):
+        """Main stream waits for the branch; `outs` are branch results the main stream will read."""
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+            for t in outs:
+                if t is not None:
+                    t.record_stream(self.main)
+
+
 class _WgradStream:
     """Context that runs weight-gradient work on the engine's side stream.
 
