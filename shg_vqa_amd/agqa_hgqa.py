@@ -195,7 +195,9 @@ class AGQA:
 
     def train_step(self, b):
         """agqaHGQA.py:262-392 for one device batch (eager launches)."""
-        self.model.train()
+        if not self.model.training:                 # nn.Module.train() walks ~1 900 modules: only on a mode change
+            self.model.train()
+        engine().training = True
         engine().conv1_cache = None
         return self._step_body(b)
 

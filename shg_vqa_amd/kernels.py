@@ -18,7 +18,13 @@ def _dt(t):
     raise TypeError("expected float32 or bfloat16 tensor, got %s" % t.dtype)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream (raw getter: ~10x cheaper than torch.cuda.current_stream())."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -25,3 +25,14 @@ for trial in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print("issue %.1f ms, drain %.1f ms, total %.1f ms" % (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t2 - t0)), flush=True)
+
+if os.environ.get("PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(3):
+        tr.train_step(batches[i % 2])
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)
