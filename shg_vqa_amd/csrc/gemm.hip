@@ -384,8 +384,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
+    // 8-wave configuration: waves w and w+4 share a SIMD.  If both run the identical sequence they issue their
+    // direct-to-LDS loads (each a multi-ten-cycle issue) and their MFMAs in lockstep and compete; the second
+    // half of the workgroup therefore issues the next stage's loads BETWEEN its two MFMA batches, so that on
+    // every SIMD one wave is in a matrix phase while its partner is in a load phase.
+    // (measured: helps the layouts with transposed LDS reads - dgrad / wgrad forms, 8-15 % - and is neutral to
+    // slightly negative when both operands are contraction-contiguous, so it is enabled per layout)
+    const bool late_loader = (WM * WN == 8) && (!SrcA::KMAJOR || !SrcB::KMAJOR) && (wave_u >= 4);
     for (int64_t kt = kt_begin; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
+        const bool has_next = kt + 1 < nk;
+        if (has_next && !late_loader) {
             stage(cur ^ 1, kt + 1);                   // lands while this step computes
             if (kt + 2 < nk) { sa.prefetch(tid, (kt + 2) * BK); sb.prefetch(tid, (kt + 2) * BK); }
         }
@@ -407,6 +415,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
             for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < JN; ++j) mma(acc[i][j], fb[j], fa[i]);   // rows = n, cols = m
+            if (ks == 0 && has_next && late_loader) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage(cur ^ 1, kt + 1);
+                if (kt + 2 < nk) { sa.prefetch(tid, (kt + 2) * BK); sb.prefetch(tid, (kt + 2) * BK); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next stage has landed ...
         __syncthreads();                                      // ... for every wave, and this one is free again
