@@ -480,7 +480,8 @@ constexpr int64_t LARGE_MIN_TILES = 128;
 
 static bool use_large(int dtype_is_bf16, int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    return dtype_is_bf16 && tiles >= LARGE_MIN_TILES && K >= 128;
+    static const int64_t min_k = []() { const char* e = getenv("SHG_LARGE_MIN_K"); return e ? (int64_t)atoi(e) : (int64_t)128; }();
+    return dtype_is_bf16 && tiles >= LARGE_MIN_TILES && K >= min_k;
 }
 
 template <typename T, typename TC, bool AK, bool BK_>
