@@ -52,21 +52,7 @@ template <typename T> struct Tile64 {
     template <bool KMAJ> __device__ __forceinline__ static int swz(int row) { return KMAJ ? (row & 7) : swz_ks(row); }
 };
 
-// Copies a 64 x 64 tile (rows beyond rows_valid are zero-filled) from global memory into a swizzled
-// LDS tile; 256 threads, 16 bytes per access.  src rows are `row_stride` elements apart.
-template <typename T>
-__device__ __forceinline__ void load_tile64(char* lds, const T* src, int64_t row_stride, int rows_valid, int tid,
-                                            int nthreads = 256) {
-    using TL = Tile64<T>;
-    for (int c = tid; c < 64 * TL::CH; c += nthreads) {
-        const int row = c / TL::CH, ch = c % TL::CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < rows_valid) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * row_stride + ch * TL::EPC);
-        *reinterpret_cast<uint4*>(lds + TL::chunk_off(row, ch)) = v;
-    }
-}
-
-// Asynchronous variant: global -> LDS directly (global_load_lds, 16 B per lane; one wave instruction
+// Stages a 64 x 64 tile global -> LDS directly (global_load_lds, 16 B per lane; one wave instruction
 // fills 64 consecutive 16-byte slots, the swizzle is applied to the per-lane SOURCE address).  Rows
 // beyond rows_valid re-read the last valid row (finite garbage the caller masks out).  The data is only
 // visible after the issuing waves' s_waitcnt vmcnt(0) and a workgroup barrier.

@@ -286,7 +286,7 @@ def gemm(a, b, out, bias=None, a_kmajor=True, b_kmajor=True, accumulate=False):
     _need(a.dtype == b.dtype, "a/b dtype mismatch")
     m, k = (a.shape if a_kmajor else (a.shape[1], a.shape[0]))
     n, k2 = (b.shape if b_kmajor else (b.shape[1], b.shape[0]))
-    _need(k == k2 or (a_kmajor and b_kmajor is False and False), "contraction size mismatch: %d vs %d" % (k, k2))
+    _need(k == k2, "contraction size mismatch: %d vs %d" % (k, k2))
     _need(out.shape == (m, n), "out must be [%d, %d]" % (m, n))
     _f32vec(bias, n, "bias")
     _lib.call("shg_gemm", a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _dt(a), _dt(out), m, n, k, a.stride(0),

@@ -393,7 +393,7 @@ def test_gemm_fragment_layout_with_integer_data(K):
 
 def test_gemm_rejects_bad_arguments(K):
     from shg_vqa_amd._lib import ShgError
-    a = torch.zeros(16, 12, device=DEV)            # K = 12 is not a multiple of 4... it is; use 10
+    a = torch.zeros(16, 12, device=DEV)
     with pytest.raises((ShgError, ValueError)):
         K.gemm(torch.zeros(16, 10, device=DEV), torch.zeros(8, 10, device=DEV), torch.zeros(16, 8, device=DEV))
     with pytest.raises((ShgError, ValueError)):
@@ -468,7 +468,7 @@ def test_gemm_split_k_accumulates_into_running_sum(K):
 
 @pytest.mark.parametrize("akm,bkm", [(True, True), (True, False), (False, True), (False, False)])
 def test_gemm_large_tile_configuration(K, akm, bkm):
-    """Shapes with >= 192 tiles of 256 x 256 take the 4x4-tile / 8-wave kernel (bf16 only)."""
+    """Shapes with >= 128 tiles of 256 x 256 take the 4x4-tile / 8-wave kernel (bf16 only)."""
     _gemm_case(K, torch.bfloat16, akm, bkm, 4104, 3080, 832, False, torch.bfloat16, with_bias=True)
     _gemm_case(K, torch.bfloat16, akm, bkm, 4096, 3072, 776, False, torch.float32, with_bias=False)
     _gemm_case(K, torch.bfloat16, akm, bkm, 3592, 3592, 520, True, torch.float32, with_bias=False)
