@@ -36,3 +36,18 @@ if os.environ.get("PROFILE"):
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
     st.sort_stats("tottime").print_stats(28)
+
+st0 = torch.cuda.memory_stats()
+for i in range(4):
+    tr.train_step(batches[i % 2])
+torch.cuda.synchronize()
+st1 = torch.cuda.memory_stats()
+print("reserved GB %.2f -> %.2f ; segment allocs %d -> %d ; peak allocated GB %.2f" % (
+    st0["reserved_bytes.all.current"] / 2**30, st1["reserved_bytes.all.current"] / 2**30,
+    st0["segment.all.allocated"], st1["segment.all.allocated"], st1["allocated_bytes.all.peak"] / 2**30), flush=True)
+
+for i in range(12):
+    tr.train_step(batches[i % 2])
+    torch.cuda.synchronize()
+    st = torch.cuda.memory_stats()
+    print("step", i, "segments", st["segment.all.allocated"], "reserved GB %.2f" % (st["reserved_bytes.all.current"] / 2**30), flush=True)
