@@ -131,6 +131,11 @@ int shg_colsum_partial(const void* x, int dtype, int64_t rows, int cols, int64_t
                        void* stream);
 /* out[c] (+)= sum_p partial[p, c]   (deterministic second stage of the column reductions) */
 int shg_colsum_finish(const float* partial, int n_partials, int cols, float* out, int accumulate, void* stream);
+/* outs[i][c] += sum_p partials[i][p, c] for i < count <= 4 equally shaped partial buffers in ONE launch: the
+ * gamma / beta / bias gradients of one LayerNorm backward (modeling_capsbert.py:431-435, :485-489).
+ * `partials` / `outs` are HOST arrays of device pointers. */
+int shg_colsum_finish_multi(const float* const* partials, float* const* outs, int count, int n_partials, int cols,
+                            void* stream);
 /* number of row-chunks (n_partials) the bwd kernels use for `rows` */
 int shg_colsum_partials(int64_t rows);
 
@@ -164,7 +169,8 @@ int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o
  *   rounded up to it; padding elements must be finite.
  *   a_kmajor = 1: A stored [M, K] (lda = row stride);  0: A stored [K, M]
  *   b_kmajor = 1: B stored [N, K] (ldb = row stride);  0: B stored [K, N]
- *   C (dtype_c: SHG_F32 or SHG_BF16) row stride ldc; accumulate != 0 adds into C (fp32 C only).
+ *   C (dtype_c: SHG_F32 or SHG_BF16) row stride ldc; accumulate != 0 adds into C (the sum is formed in fp32
+ *   and rounded once: weight gradients into the fp32 arena, input gradients onto a residual gradient).
  *   Weight-gradient shapes (both operands contraction-strided, accumulate) with few output tiles are
  *   split along K over several workgroups whose partial sums are added with fp32 atomics.
  *   forward  y = x W^T : a_kmajor=1 (x), b_kmajor=1 (W [N,K])
@@ -174,6 +180,13 @@ int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o
 int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
              int accumulate, void* stream);
+/* C = act(A . B + bias) with the activation in the epilogue and, when `pre` is given, the pre-activation
+ * values A . B + bias written to pre [M, N] (row stride N, dtype_c) for the backward pass: BertIntermediate's
+ * Linear + erf-GELU (modeling_capsbert.py:472-475, :127-133) and the heads' Linear + GELU (agqa_model.py:105-110)
+ * as one kernel.  act: SHG_ACT_*. */
+int shg_gemm_act(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
+                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, int act,
+                 void* pre, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Conv3d with kernel (5,3,3), "valid" in T, zero padding 1 in H and W, as an implicit GEMM over a

@@ -30,11 +30,13 @@ _SIGNATURES = {
     "shg_bias_act_drop_res_ln_bwd": ([P, P, P, P, P, P, P, P, P, P, P, P, I, I, L, I, I, F, P, U, P], c_int),
     "shg_colsum_partial": ([P, I, L, I, L, P, I, P], c_int),
     "shg_colsum_finish": ([P, I, I, P, I, P], c_int),
+    "shg_colsum_finish_multi": ([P, P, I, I, I, P], c_int),
     "shg_colsum_partials": ([L], c_int),
     "shg_attention_fwd": ([P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, I, P, F, F, P, U, P], c_int),
     "shg_attention_bwd": ([P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, L,
                            I, P, F, F, P, U, P], c_int),
     "shg_gemm": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P], c_int),
+    "shg_gemm_act": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P, P], c_int),
     "shg_conv3d_k533_workspace_bytes": ([I, I, I, I], c_int64),
     "shg_conv3d_k533_prepare": ([P, I, I, I, I, P], c_int),
     "shg_conv3d_k533_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P], c_int),

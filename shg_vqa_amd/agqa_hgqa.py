@@ -187,6 +187,7 @@ class AGQA:
             self.world.begin_step()
         out = self.forward_losses(b)
         out["total"].backward()
+        ops.flush_wgrads()                          # weight gradients still queued (Engine.wgrad_batch)
         if self.world is not None:
             self.world.finish()
         out["grad_norm"] = clip_grad_norm_(self.model.parameters(), 5.0)

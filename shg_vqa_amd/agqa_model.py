@@ -151,7 +151,9 @@ class AGQAModel(nn.Module):
         for name, mod in self.named_modules():
             if isinstance(mod, M.BertAttention):
                 groups += mod.fusion_groups(name + ".")
-                mod._fz = None
+            for slot in ("_fz", "_ap", "_fp", "_fl", "_fv", "_sp"):      # cached operand handles refer to arena offsets
+                if slot in mod.__dict__:
+                    mod.__dict__[slot] = None
         # shared modules are registered under several names: keep the groups whose names are canonical
         canon = {n for n, _ in self.named_parameters()}
         groups = [g for g in groups if all(n in canon for n in g)]

@@ -235,13 +235,22 @@ template <> struct RowWriter<bf16_t> {
             bf16_t* pre = ep.pre ? ep.pre + m * N + n : nullptr;
             if (nv == 8 && ep.vec_ok) {
                 bf16x8 o, q;
+                if (ep.accumulate) {                       // C += A.B in fp32, rounded once (residual-gradient sums)
+                    const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) { q[r] = (bf16_t)u[r]; o[r] = (bf16_t)apply_act(u[r], ep.act); }
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(apply_act(u[r], ep.act) + (float)old[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)apply_act(u[r], ep.act);
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) q[r] = (bf16_t)u[r];
                 *reinterpret_cast<bf16x8*>(dst) = o;
                 if (pre) *reinterpret_cast<bf16x8*>(pre) = q;
             } else {
                 for (int r = 0; r < nv; ++r) {
-                    dst[r] = (bf16_t)apply_act(u[r], ep.act);
+                    const float x = apply_act(u[r], ep.act);
+                    dst[r] = (bf16_t)(ep.accumulate ? x + (float)dst[r] : x);
                     if (pre) pre[r] = (bf16_t)u[r];
                 }
             }
@@ -554,14 +563,15 @@ using namespace shg;
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
-                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
-                        int accumulate, void* stream) {
+static int gemm_entry(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
+                      int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
+                      int accumulate, int act, void* pre, void* stream) {
     if (!a || !b || !c) return fail_arg("gemm: null pointer");
     if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm: sizes must be positive");
     if ((dtype_ab != SHG_F32 && dtype_ab != SHG_BF16) || (dtype_c != SHG_F32 && dtype_c != SHG_BF16)) return fail_arg("gemm: bad dtype");
     if (dtype_ab == SHG_F32 && dtype_c == SHG_BF16) return fail_arg("gemm: fp32 operands need an fp32 C");
-    if (accumulate && dtype_c != SHG_F32) return fail_arg("gemm: accumulate needs an fp32 C");
+    if (act < 0 || act > 2) return fail_arg("gemm: bad activation");
+    if (accumulate && (act != SHG_ACT_NONE || pre)) return fail_arg("gemm: accumulate excludes an activation / pre-activation output");
     const int epc = dtype_ab == SHG_BF16 ? 8 : 4;
     if (!al16(a) || !al16(b)) return fail_arg("gemm: A and B must be 16-byte aligned");
     if (lda % epc || ldb % epc) return fail_arg("gemm: lda/ldb must keep rows 16-byte aligned");
@@ -572,14 +582,28 @@ extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias
     if (lda < ea || ldb < eb || ldc < N) return fail_arg("gemm: leading dimension too small for 16-byte row reads");
     hipStream_t st = (hipStream_t)stream;
     const int vlen = dtype_c == SHG_F32 ? 4 : 8;      // elements per 16-byte output vector
-    const int vec_ok = (ldc % vlen == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
+    const int vec_ok = (ldc % vlen == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) &&
+                       (!pre || ((N % vlen == 0) && al16(pre)));
     if (dtype_c == SHG_F32) {
-        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, SHG_ACT_NONE, accumulate, vec_ok, nullptr, 0};
+        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (float*)pre, 0};
         return dtype_ab == SHG_F32 ? gemm_dispatch<float, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st)
                                    : gemm_dispatch<bf16_t, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
     }
-    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, SHG_ACT_NONE, 0, vec_ok, nullptr, 0};
+    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
+}
+
+extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
+                        int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
+                        int accumulate, void* stream) {
+    return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, SHG_ACT_NONE,
+                      nullptr, stream);
+}
+
+extern "C" int shg_gemm_act(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
+                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
+                            int act, void* pre, void* stream) {
+    return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 0, act, pre, stream);
 }
 
 extern "C" int64_t shg_conv3d_k533_workspace_bytes(int B, int T, int H, int W) {

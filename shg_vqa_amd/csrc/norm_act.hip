@@ -322,6 +322,33 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __rest
     }
 }
 
+// up to four reductions of equally shaped partial buffers in one launch (blockIdx.z picks the pair):
+// the gamma / beta / bias gradients of one LayerNorm backward
+struct FinishSet {
+    const float* partial[4];
+    float* out[4];
+};
+__global__ __launch_bounds__(1024) void colsum_finish_multi_kernel(FinishSet fs, int n_partials, int cols) {
+    __shared__ float sh[16][64];
+    const float* __restrict__ partial = fs.partial[blockIdx.z];
+    float* __restrict__ out = fs.out[blockIdx.z];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int per = (n_partials + gridDim.y - 1) / gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = min(n_partials, p0 + per);
+    float s = 0.f;
+    if (c < cols)
+        for (int p = p0 + ty; p < p1; p += 16) s += partial[(int64_t)p * cols + c];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < cols && p0 < p1) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][tx];
+        atomicAdd(out + c, t);
+    }
+}
+
 template <typename T> static bool aligned16(const T* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T>
@@ -398,6 +425,21 @@ extern "C" int shg_colsum_finish(const float* partial, int n_partials, int cols,
     const int slices = n_partials >= 256 ? 8 : (n_partials >= 64 ? 4 : 1);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 63) / 64, slices), dim3(1024), 0, st, partial, n_partials, cols, out);
     return check_launch("colsum_finish");
+}
+
+extern "C" int shg_colsum_finish_multi(const float* const* partials, float* const* outs, int count, int n_partials, int cols,
+                                       void* stream) {
+    if (!partials || !outs || count < 1 || count > 4 || n_partials < 1 || cols < 1) return fail_arg("colsum_finish_multi: bad argument");
+    FinishSet fs{};
+    for (int i = 0; i < count; ++i) {
+        if (!partials[i] || !outs[i]) return fail_arg("colsum_finish_multi: null pointer");
+        fs.partial[i] = partials[i];
+        fs.out[i] = outs[i];
+    }
+    const int slices = n_partials >= 256 ? 8 : (n_partials >= 64 ? 4 : 1);
+    hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3((cols + 63) / 64, slices, count), dim3(1024), 0, (hipStream_t)stream, fs,
+                       n_partials, cols);
+    return check_launch("colsum_finish_multi");
 }
 
 extern "C" int shg_bias_act_drop_res_ln_fwd(const void* x, const float* bias, const void* residual, const float* gamma,

@@ -14,6 +14,8 @@ element offset.  Consequences:
     permuted view, so checkpoints keep the reference's keys and shapes.
 nn.Parameters become views into the arenas; `p.grad` is a persistent view of the gradient arena.
 """
+import os
+
 import torch
 
 _ENGINE = None
@@ -50,9 +52,12 @@ class Engine:
         self.training = False            # dropout on/off; set by AGQAModel.train()/eval()
         self.grad_ready_hook = None      # set by ddp: called with (offset, numel) after a gradient write
         self.model = None
-        self.overlap_wgrad = True         # weight gradients on a side stream (ops._WgradStream)
+        # SHG_OVERLAP_WGRAD / SHG_OVERLAP_BRANCHES = 0 turn the side streams off (measurement switches)
+        self.overlap_wgrad = os.environ.get("SHG_OVERLAP_WGRAD", "1") != "0"      # weight gradients on a side stream (ops._WgradStream)
         self._wgrad_stream = None
-        self.overlap_branches = True      # independent sub-graphs (action decoder, language layers) on side streams
+        self.wgrad_batch = int(os.environ.get("SHG_WGRAD_BATCH", "1"))   # layers per fork of the weight-gradient stream
+        self.deferred_wgrads = []
+        self.overlap_branches = os.environ.get("SHG_OVERLAP_BRANCHES", "1") != "0"   # independent sub-graphs (action decoder, language layers) on side streams
         self._aux_streams = {}
         self.kernel_events = None        # bench.py: list collecting (start, end) events of the dominant kernel
         self.pending_clip = None
@@ -159,6 +164,9 @@ class Engine:
 
     def join_side_streams(self):
         """Makes the current stream wait for all weight-gradient work issued so far."""
+        if self.deferred_wgrads:
+            from . import ops
+            ops.flush_wgrads()
         cur = torch.cuda.current_stream()
         for s in self.side_streams():
             cur.wait_stream(s)

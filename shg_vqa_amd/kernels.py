@@ -4,6 +4,8 @@ Each function validates shapes / dtypes / contiguity on the host BEFORE the laun
 faults can take the whole GPU host down) and then hands raw pointers to libshgvqa.so.
 torch is used for allocation and stream plumbing only.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -144,6 +146,16 @@ def colsum(x2d, out, accumulate):
     colsum_finish(part, out, accumulate)
 
 
+def colsum_finish_multi(partials, outs):
+    """outs[i] += column sums of partials[i] ([n_partials, cols] each, same shape), one launch for up to 4 pairs."""
+    n = len(partials)
+    _need(1 <= n <= 4 and len(outs) == n, "1..4 (partial, out) pairs")
+    n_partials, cols = partials[0].shape
+    arr = ctypes.c_void_p * n
+    _lib.call("shg_colsum_finish_multi", arr(*[t.data_ptr() for t in partials]), arr(*[t.data_ptr() for t in outs]), n,
+              n_partials, cols, _stream())
+
+
 def colsum_finish(partial, out, accumulate):
     n_partials, cols = partial.shape
     _need(out.numel() == cols and out.dtype == torch.float32 and out.is_contiguous(), "out must be fp32 [cols]")
@@ -206,9 +218,9 @@ def ln_bwd(dy, z, x, bias, gamma, mean, rstd, act=ACT_NONE, p_drop=0.0, seed_sta
     npart = colsum_partials(rows)
     dx = torch.empty_like(dy) if want_dx else None
     dres = torch.empty_like(dy) if want_dres else None
-    dg = torch.empty((npart, cols), dtype=torch.float32, device=dy.device)
-    db = torch.empty_like(dg)
-    dbi = torch.empty_like(dg) if want_dbias else None
+    parts = torch.empty((3 if want_dbias else 2, npart, cols), dtype=torch.float32, device=dy.device)
+    dg, db = parts[0], parts[1]
+    dbi = parts[2] if want_dbias else None
     _lib.call("shg_bias_act_drop_res_ln_bwd", dy.data_ptr(), z.data_ptr(), _p(x), _p(bias), gamma.data_ptr(),
               mean.data_ptr(), rstd.data_ptr(), _p(dx), _p(dres), dg.data_ptr(), db.data_ptr(), _p(dbi), npart, _dt(dy),
               rows, cols, act, float(p_drop), _p(seed_state), int(stream_id), _stream())
@@ -277,6 +289,20 @@ def attention_bwd(q, k, v, o, d_o, lse, dq, dk, dv, heads, mask_kind=MASK_NONE, 
 
 
 # ------------------------------------------------------------------------------------------------
+def gemm_act(a, b, out, bias, act, pre=None):
+    """out = act(a . b^T + bias) in one kernel (a [M,K], b [N,K]); pre [M,N] receives a . b^T + bias."""
+    m, k = a.shape
+    n = b.shape[0]
+    _need(a.dtype == b.dtype and b.shape[1] == k and out.shape == (m, n) and out.stride(1) == 1 and a.stride(1) == 1
+          and b.stride(1) == 1, "gemm_act: shape / layout mismatch")
+    if pre is not None:
+        _need(pre.shape == (m, n) and pre.is_contiguous() and pre.dtype == out.dtype, "pre must be contiguous [M, N] of out's dtype")
+    _f32vec(bias, n, "bias")
+    _lib.call("shg_gemm_act", a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _dt(a), _dt(out), m, n, k, a.stride(0),
+              b.stride(0), out.stride(0), 1, 1, int(act), _p(pre), _stream())
+    return out
+
+
 def gemm(a, b, out, bias=None, a_kmajor=True, b_kmajor=True, accumulate=False):
     """out[M,N] (+)= A . B (+ bias).  a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N].
     2-D tensors with unit inner stride (row stride = leading dimension)."""

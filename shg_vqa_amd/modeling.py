@@ -185,9 +185,19 @@ class BertCrossattLayer(nn.Module):
         self.att = BertAttention(config)
         self.output = BertAttOutput(config)
 
+    def _params(self):
+        if getattr(self, "_ap", None) is None:
+            a, out = self.att, self.output
+            _, _, w_kv, b_kv = a._fused()
+            self._ap = ops.AttnParams("cross", a.query.weight, a.query.bias, w_kv, b_kv, out.dense.weight, out.dense.bias,
+                                      out.LayerNorm.weight, out.LayerNorm.bias, 1e-12, a.num_attention_heads,
+                                      1.0 / math.sqrt(a.attention_head_size), a.dropout.p, out.dropout.p)
+        return self._ap
+
     def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None):
-        o, probs = self.att(input_tensor, ctx_tensor, ctx_att_mask)
-        return self.output(o, input_tensor), probs
+        """Attention + output projection + residual LayerNorm as one fused sub-layer (ops.attn_sublayer)."""
+        kind, mask = key_mask_2d(ctx_att_mask)
+        return ops.attn_sublayer(input_tensor, None, ctx_tensor, self._params(), kind, mask), None
 
 
 class BertSelfattLayer(nn.Module):
@@ -198,9 +208,19 @@ class BertSelfattLayer(nn.Module):
         self.self = BertAttention(config)
         self.output = BertAttOutput(config)
 
+    def _params(self):
+        if getattr(self, "_ap", None) is None:
+            a, out = self.self, self.output
+            w_qkv, b_qkv, _, _ = a._fused()
+            self._ap = ops.AttnParams("self", w_qkv, b_qkv, None, None, out.dense.weight, out.dense.bias,
+                                      out.LayerNorm.weight, out.LayerNorm.bias, 1e-12, a.num_attention_heads,
+                                      1.0 / math.sqrt(a.attention_head_size), a.dropout.p, out.dropout.p)
+        return self._ap
+
     def forward(self, input_tensor, attention_mask):
-        o, probs = self.self(input_tensor, input_tensor, attention_mask)
-        return self.output(o, input_tensor), probs
+        """Attention + output projection + residual LayerNorm as one fused sub-layer (ops.attn_sublayer)."""
+        kind, mask = key_mask_2d(attention_mask)
+        return ops.attn_sublayer(input_tensor, None, None, self._params(), kind, mask), None
 
 
 class BertIntermediate(nn.Module):
@@ -229,6 +249,16 @@ class BertOutput(nn.Module):
                                       1e-12, ops.ACT_NONE, self.dropout.p)
 
 
+def ffn_params(owner, inter, out, slot="_fp"):
+    """ops.FFNParams of a BertIntermediate + BertOutput pair, cached on `owner`."""
+    P = getattr(owner, slot, None)
+    if P is None:
+        P = ops.FFNParams(inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias, out.LayerNorm.weight,
+                          out.LayerNorm.bias, 1e-12, ops.ACT_GELU, 0.0, out.dropout.p)
+        object.__setattr__(owner, slot, P)
+    return P
+
+
 class BertLayer(nn.Module):
     """mc:492-503."""
 
@@ -240,7 +270,7 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask):
         a, probs = self.attention(hidden_states, attention_mask)
-        return self.output(self.intermediate(a), a), probs
+        return ops.ffn_sublayer(a, ffn_params(self, self.intermediate, self.output)), probs
 
 
 class CrossLayer(nn.Module):
@@ -261,8 +291,8 @@ class CrossLayer(nn.Module):
         return la, va, pl, pv
 
     def output_fc(self, lang_input, visn_input):
-        return (self.lang_output(self.lang_inter(lang_input), lang_input),
-                self.visn_output(self.visn_inter(visn_input), visn_input))
+        return (ops.ffn_sublayer(lang_input, ffn_params(self, self.lang_inter, self.lang_output, "_fl")),
+                ops.ffn_sublayer(visn_input, ffn_params(self, self.visn_inter, self.visn_output, "_fv")))
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask, last=None):
         la, va, pl, pv = self.cross_att(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)

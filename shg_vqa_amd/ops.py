@@ -119,9 +119,18 @@ class _WgradStream:
 
 
 def _wgrad(dy2, x2, weight, bias):
-    """Accumulates dW += dy^T x and db += colsum(dy) into the gradient arena (on the side stream)."""
+    """Accumulates dW += dy^T x and db += colsum(dy) into the gradient arena (on the side stream).
+
+    With Engine.wgrad_batch > 1 the work is queued and issued `wgrad_batch` layers at a time
+    (flush_wgrads): one fork event per batch instead of one per layer keeps the dependency graph coarse
+    (a captured hipGraph only runs coarse branches concurrently) and saves host time in eager mode."""
     E = engine()
     if weight._shg_grad is None:
+        return
+    if E.wgrad_batch > 1 and E.wgrad_stream() is not None:
+        E.deferred_wgrads.append((torch.cuda.current_stream(), dy2, x2, weight, bias))
+        if len(E.deferred_wgrads) >= E.wgrad_batch:
+            flush_wgrads()
         return
     with _WgradStream(dy2, x2):
         K.gemm(dy2, x2, weight._shg_grad, None, False, False, accumulate=True)
@@ -130,6 +139,32 @@ def _wgrad(dy2, x2, weight, bias):
     E.grad_written(weight)
     if bias is not None:
         E.grad_written(bias)
+
+
+def flush_wgrads():
+    """Issues the queued weight gradients on the side stream, behind everything their producer streams
+    have enqueued so far."""
+    E = engine()
+    q, E.deferred_wgrads = E.deferred_wgrads, []
+    if not q:
+        return
+    side = E.wgrad_stream()
+    seen = []
+    for st, *_ in q:
+        if all(st != o for o in seen):
+            seen.append(st)
+            side.wait_stream(st)
+    with torch.cuda.stream(side):
+        for _, dy2, x2, weight, bias in q:
+            K.gemm(dy2, x2, weight._shg_grad, None, False, False, accumulate=True)
+            if bias is not None:
+                K.colsum(dy2, bias._shg_grad.view(-1), True)
+    for _, dy2, x2, weight, bias in q:
+        dy2.record_stream(side)
+        x2.record_stream(side)
+        E.grad_written(weight)
+        if bias is not None:
+            E.grad_written(bias)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -686,3 +721,235 @@ def self_attention_qkv(x, w_qkv, b_qkv, heads, mask_kind, mask, scale, p_drop):
 
 def cross_attention_qkv(h, c, w_q, b_q, w_kv, b_kv, heads, mask_kind, mask, scale, p_drop):
     return _CrossAttnQKV.apply(h, c, _anchor(w_q), w_q, b_q, w_kv, b_kv, heads, mask_kind, mask, scale, p_drop)
+
+
+# ------------------------------------------------------------------------------------------------
+# Whole sub-layers as ONE autograd node each.  The forward / backward bodies are the same kernel
+# sequences as the small ops above, but (i) the residual gradient and the projection's input gradient
+# are summed by the dgrad GEMM's accumulate epilogue instead of an extra add kernel, (ii) the
+# LayerNorm's gamma / beta / bias column sums finish in one launch, (iii) Linear + GELU is one kernel,
+# and (iv) a sub-layer costs one autograd node instead of four (host time matters: a step is ~1 300
+# launches).
+# ------------------------------------------------------------------------------------------------
+def _finish_ln_grads(dg, db, dbi, gamma, beta, bias):
+    E = engine()
+    parts, outs, ps = [], [], []
+    if gamma._shg_grad is not None:
+        parts += [dg, db]
+        outs += [gamma._shg_grad.view(-1), beta._shg_grad.view(-1)]
+        ps += [gamma, beta]
+    if dbi is not None and bias is not None and bias._shg_grad is not None:
+        parts.append(dbi)
+        outs.append(bias._shg_grad.view(-1))
+        ps.append(bias)
+    if parts:
+        K.colsum_finish_multi(parts, outs)
+        for q in ps:
+            E.grad_written(q)
+
+
+def _c2(t):
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2 if t2.is_contiguous() else t2.contiguous()
+
+
+class FFNParams:
+    """Parameter handles + constants of a position-wise feed-forward sub-layer."""
+
+    def __init__(self, w1, b1, w2, b2, gamma, beta, eps, act, p_inner, p_out):
+        self.w1, self.b1, self.w2, self.b2, self.gamma, self.beta = w1, b1, w2, b2, gamma, beta
+        self.eps, self.act, self.p_inner, self.p_out = eps, act, p_inner, p_out
+
+
+class _FFNSublayer(torch.autograd.Function):
+    """y = LayerNorm(x + drop_out(W2 drop_in(act(W1 x + b1)) + b2)):
+    BertIntermediate + BertOutput (mc:463-489; GELU, no inner dropout) and the decoder's
+    linear1 / ReLU / dropout / linear2 / dropout3 / norm3 (transformer.py:230-232)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, P):
+        E = engine()
+        x2 = _c2(x)
+        rows, H = x2.shape
+        F = P.w1.shape[0]
+        dev, dt = x2.device, x2.dtype
+        pi, seed_i, sid_i = _drop_args(P.p_inner)
+        po, seed_o, sid_o = _drop_args(P.p_out)
+        pre = torch.empty((rows, F), dtype=dt, device=dev)
+        fused = pi == 0.0
+        if fused:                                   # Linear + bias + activation in the GEMM epilogue
+            h = torch.empty((rows, F), dtype=dt, device=dev)
+            K.gemm_act(x2, E.operand(P.w1), h, P.b1._shg_store.view(-1), P.act, pre)
+        else:
+            K.gemm(x2, E.operand(P.w1), pre, None, True, True)
+            h = K.bias_act_fwd(pre, P.b1._shg_store.view(-1), P.act, pi, seed_i, sid_i)
+        t = torch.empty((rows, H), dtype=dt, device=dev)
+        K.gemm(h, E.operand(P.w2), t, None, True, True)
+        y, z, mean, rstd = K.ln_fwd(t, P.b2._shg_store.view(-1), x2, P.gamma._shg_store, P.beta._shg_store, P.eps,
+                                    ACT_NONE, po, seed_o, sid_o, save_z=True)
+        ctx.save_for_backward(x2, pre, h, z, mean, rstd)
+        ctx.P, ctx.cfg = P, (fused, pi, seed_i, sid_i, po, seed_o, sid_o, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre, h, z, mean, rstd = ctx.saved_tensors
+        P = ctx.P
+        fused, pi, seed_i, sid_i, po, seed_o, sid_o, shape = ctx.cfg
+        E = engine()
+        want_b2 = P.b2._shg_grad is not None
+        dt_, dres, dg, db, dbi = K.ln_bwd(_c2(dy), z, None, P.b2._shg_store.view(-1), P.gamma._shg_store, mean, rstd,
+                                          ACT_NONE, po, seed_o, sid_o, want_dx=True, want_dres=True, want_dbias=want_b2)
+        _finish_ln_grads(dg, db, dbi, P.gamma, P.beta, P.b2)
+        _wgrad(dt_, h, P.w2, None)
+        dh = torch.empty_like(h)
+        K.gemm(dt_, E.operand(P.w2), dh, None, True, False)
+        want_b1 = P.b1._shg_grad is not None
+        dpre, part = K.bias_act_bwd(pre, None if fused else P.b1._shg_store.view(-1), dh, P.act, pi, seed_i, sid_i,
+                                    want_dbias=want_b1)
+        if want_b1:
+            _acc_vec(part, P.b1)
+        _wgrad(dpre, x2, P.w1, None)
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        K.gemm(dpre, E.operand(P.w1), dres, None, True, False, accumulate=True)      # dx = dres + dpre W1
+        return dres.view(shape), None, None
+
+
+def ffn_sublayer(x, P):
+    return _FFNSublayer.apply(x, _anchor(P.gamma), P)
+
+
+class AttnParams:
+    """Parameter handles + constants of an attention sub-layer.
+    mode: 'self'      q, k, v = W_in x                      (one GEMM, N = 3H; BertSelfattLayer mc:450-460)
+          'cross'     q = W_q x ; k, v = W_kv mem           (BertCrossattLayer mc:438-447)
+          'dec_self'  q, k = W_qk (x + pos) ; v = W_v x     (transformer.py:216-219)
+          'dec_cross' q = W_q (x + pos) ; k, v = W_kv mem   (transformer.py:222-226)
+    w_a / b_a: rows of the in-projection applied to the first source, w_b / b_b: rows applied to the second."""
+
+    def __init__(self, mode, w_a, b_a, w_b, b_b, w_o, b_o, gamma, beta, eps, heads, scale, p_attn, p_out):
+        self.mode, self.w_a, self.b_a, self.w_b, self.b_b, self.w_o, self.b_o = mode, w_a, b_a, w_b, b_b, w_o, b_o
+        self.gamma, self.beta, self.eps, self.heads, self.scale, self.p_attn, self.p_out = gamma, beta, eps, heads, scale, p_attn, p_out
+
+
+class _AttnSublayer(torch.autograd.Function):
+    """y = LayerNorm(x + drop_out(W_o attention(...) + b_o)), see AttnParams for the four projection layouts."""
+
+    @staticmethod
+    def forward(ctx, x, pos, mem, anchor, P, mask_kind, mask):
+        E = engine()
+        mode = P.mode
+        B, Sq, H = x.shape
+        x2 = _c2(x)
+        dev, dt = x2.device, x2.dtype
+        pa, seed_a, sid_a = _drop_args(P.p_attn)
+        po, seed_o, sid_o = _drop_args(P.p_out)
+        xp2 = mem2 = None
+        if mode in ("dec_self", "dec_cross"):
+            xp2 = _c2(x + pos)
+        if mode in ("cross", "dec_cross"):
+            Sk = mem.shape[1]
+            mem2 = _c2(mem)
+        else:
+            Sk = Sq
+        wa, ba = E.operand(P.w_a), P.b_a._shg_store.view(-1)
+        if mode == "self":
+            qkv = torch.empty((B * Sq, 3 * H), dtype=dt, device=dev)
+            K.gemm(x2, wa, qkv, ba, True, True)
+            kvb = qkv
+            q3 = qkv.view(B, Sq, 3 * H)
+            q, k, v = q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:]
+        elif mode == "dec_self":
+            qkv = torch.empty((B * Sq, 3 * H), dtype=dt, device=dev)
+            K.gemm(xp2, wa, qkv[:, :2 * H], ba, True, True)
+            K.gemm(x2, E.operand(P.w_b), qkv[:, 2 * H:], P.b_b._shg_store.view(-1), True, True)
+            kvb = qkv
+            q3 = qkv.view(B, Sq, 3 * H)
+            q, k, v = q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:]
+        else:
+            qkv = torch.empty((B * Sq, H), dtype=dt, device=dev)
+            kvb = torch.empty((B * Sk, 2 * H), dtype=dt, device=dev)
+            K.gemm(xp2 if mode == "dec_cross" else x2, wa, qkv, ba, True, True)
+            K.gemm(mem2, E.operand(P.w_b), kvb, P.b_b._shg_store.view(-1), True, True)
+            q = qkv.view(B, Sq, H)
+            kv3 = kvb.view(B, Sk, 2 * H)
+            k, v = kv3[:, :, :H], kv3[:, :, H:]
+        o, lse = K.attention_fwd(q, k, v, P.heads, mask_kind, mask, P.scale, pa, seed_a, sid_a)
+        o2 = o.view(B * Sq, H)
+        t = torch.empty((B * Sq, H), dtype=dt, device=dev)
+        K.gemm(o2, E.operand(P.w_o), t, None, True, True)
+        y, z, mean, rstd = K.ln_fwd(t, P.b_o._shg_store.view(-1), x2, P.gamma._shg_store, P.beta._shg_store, P.eps,
+                                    ACT_NONE, po, seed_o, sid_o, save_z=True)
+        ctx.save_for_backward(x2, xp2, mem2, qkv, kvb if kvb is not qkv else None, o, lse, z, mean, rstd)
+        ctx.P = P
+        ctx.cfg = (mask_kind, mask, pa, seed_a, sid_a, po, seed_o, sid_o, (B, Sq, Sk, H))
+        return y.view(B, Sq, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xp2, mem2, qkv, kvb, o, lse, z, mean, rstd = ctx.saved_tensors
+        P = ctx.P
+        mode = P.mode
+        mask_kind, mask, pa, seed_a, sid_a, po, seed_o, sid_o, (B, Sq, Sk, H) = ctx.cfg
+        E = engine()
+        want_bo = P.b_o._shg_grad is not None
+        dt_, dres, dg, db, dbi = K.ln_bwd(_c2(dy), z, None, P.b_o._shg_store.view(-1), P.gamma._shg_store, mean, rstd,
+                                          ACT_NONE, po, seed_o, sid_o, want_dx=True, want_dres=True, want_dbias=want_bo)
+        _finish_ln_grads(dg, db, dbi, P.gamma, P.beta, P.b_o)
+        o2 = o.view(B * Sq, H)
+        _wgrad(dt_, o2, P.w_o, None)
+        d_o = torch.empty_like(o2)
+        K.gemm(dt_, E.operand(P.w_o), d_o, None, True, False)
+        d_o3 = d_o.view(B, Sq, H)
+        wa = E.operand(P.w_a)
+        need_x, need_pos, need_mem = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dpos = dmem = None
+        if mode in ("self", "dec_self"):
+            q3 = qkv.view(B, Sq, 3 * H)
+            dqkv = torch.empty_like(qkv)
+            d3 = dqkv.view(B, Sq, 3 * H)
+            K.attention_bwd(q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:], o, d_o3, lse, d3[:, :, :H], d3[:, :, H:2 * H],
+                            d3[:, :, 2 * H:], P.heads, mask_kind, mask, P.scale, pa, seed_a, sid_a)
+            if mode == "self":
+                _wgrad(dqkv, x2, P.w_a, P.b_a)
+                if need_x:
+                    K.gemm(dqkv, wa, dres, None, True, False, accumulate=True)
+            else:
+                dqk, dv = dqkv[:, :2 * H], dqkv[:, 2 * H:]
+                _wgrad(dqk, xp2, P.w_a, P.b_a)
+                _wgrad(dv, x2, P.w_b, P.b_b)
+                if need_x or need_pos:
+                    dxp = torch.empty_like(x2)
+                    K.gemm(dqk, wa, dxp, None, True, False)
+                    if need_x:
+                        K.gemm(dv, E.operand(P.w_b), dres, None, True, False, accumulate=True)
+                        dres.add_(dxp)
+                    dpos = dxp.view(B, Sq, H) if need_pos else None
+        else:
+            kv3 = kvb.view(B, Sk, 2 * H)
+            dq = torch.empty_like(qkv)
+            dkv = torch.empty_like(kvb)
+            dkv3 = dkv.view(B, Sk, 2 * H)
+            K.attention_bwd(qkv.view(B, Sq, H), kv3[:, :, :H], kv3[:, :, H:], o, d_o3, lse, dq.view(B, Sq, H),
+                            dkv3[:, :, :H], dkv3[:, :, H:], P.heads, mask_kind, mask, P.scale, pa, seed_a, sid_a)
+            _wgrad(dq, xp2 if mode == "dec_cross" else x2, P.w_a, P.b_a)
+            _wgrad(dkv, mem2, P.w_b, P.b_b)
+            if mode == "cross":
+                if need_x:
+                    K.gemm(dq, wa, dres, None, True, False, accumulate=True)
+            elif need_x or need_pos:
+                dxp = torch.empty_like(x2)
+                K.gemm(dq, wa, dxp, None, True, False)
+                if need_x:
+                    dres.add_(dxp)
+                dpos = dxp.view(B, Sq, H) if need_pos else None
+            if need_mem:
+                dmem = torch.empty_like(mem2)
+                K.gemm(dkv, E.operand(P.w_b), dmem, None, True, False)
+                dmem = dmem.view(B, Sk, H)
+        return (dres.view(B, Sq, H) if need_x else None), dpos, dmem, None, None, None, None
+
+
+def attn_sublayer(x, pos, mem, P, mask_kind=K.MASK_NONE, mask=None):
+    return _AttnSublayer.apply(x, pos, mem, _anchor(P.gamma), P, mask_kind, mask)

@@ -67,22 +67,30 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
         self.normalize_before = normalize_before
 
+    def _params(self):
+        if getattr(self, "_sp", None) is None:
+            E, p = self.self_attn.embed_dim, self.dropout.p
+            sa, ca = self.self_attn, self.multihead_attn
+            w_qk, b_qk = sa.rows(0, 2 * E)
+            w_v, b_v = sa.rows(2 * E, 3 * E)
+            w_q, b_q = ca.rows(0, E)
+            w_kv, b_kv = ca.rows(E, 3 * E)
+            self._sp = (
+                ops.AttnParams("dec_self", w_qk, b_qk, w_v, b_v, sa.out_proj.weight, sa.out_proj.bias, self.norm1.weight,
+                               self.norm1.bias, self.norm1.eps, sa.num_heads, 0.125, sa.dropout, self.dropout1.p),
+                ops.AttnParams("dec_cross", w_q, b_q, w_kv, b_kv, ca.out_proj.weight, ca.out_proj.bias, self.norm2.weight,
+                               self.norm2.bias, self.norm2.eps, ca.num_heads, 0.125, ca.dropout, self.dropout2.p),
+                ops.FFNParams(self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                              self.norm3.weight, self.norm3.bias, self.norm3.eps, ops.ACT_RELU, p, self.dropout3.p))
+        return self._sp
+
     def forward_bf(self, tgt, memory, query_pos, tgt_mask):
-        """Batch-first forward_post (transformer.py:212-233)."""
-        p = self.dropout.p
-        qk_in = tgt + query_pos
-        a = self.self_attn.attend(qk_in, qk_in, tgt, tgt_mask, same_qk=True)
-        t2 = ops.linear(a, self.self_attn.out_proj.weight, None)
-        tgt = ops.bias_res_layernorm(t2, self.self_attn.out_proj.bias, tgt, self.norm1.weight, self.norm1.bias,
-                                     self.norm1.eps, ops.ACT_NONE, p)
-        a = self.multihead_attn.attend(tgt + query_pos, memory, memory, None, same_qk=False)
-        t2 = ops.linear(a, self.multihead_attn.out_proj.weight, None)
-        tgt = ops.bias_res_layernorm(t2, self.multihead_attn.out_proj.bias, tgt, self.norm2.weight, self.norm2.bias,
-                                     self.norm2.eps, ops.ACT_NONE, p)
-        h = ops.bias_act(ops.linear(tgt, self.linear1.weight, None), self.linear1.bias, ops.ACT_RELU, p)
-        t2 = ops.linear(h, self.linear2.weight, None)
-        return ops.bias_res_layernorm(t2, self.linear2.bias, tgt, self.norm3.weight, self.norm3.bias, self.norm3.eps,
-                                      ops.ACT_NONE, p)
+        """Batch-first forward_post (transformer.py:212-233): three fused sub-layers."""
+        p_self, p_cross, p_ffn = self._params()
+        kind = K.MASK_FULL if tgt_mask is not None else K.MASK_NONE
+        tgt = ops.attn_sublayer(tgt, query_pos, None, p_self, kind, tgt_mask)
+        tgt = ops.attn_sublayer(tgt, query_pos, memory, p_cross, K.MASK_NONE, None)
+        return ops.ffn_sublayer(tgt, p_ffn)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):

@@ -487,3 +487,48 @@ def test_gemm_large_tile_integer_layout(K):
             out = torch.empty(M, N, device=DEV)
             K.gemm(aa, bb, out, None, akm, bkm)
             assert torch.equal(out.cpu(), ref), (akm, bkm)
+
+
+# ------------------------------------------------------------------------------------------ fused epilogues
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_act_epilogue_and_pre_activation(K, dtype, act):
+    gen = torch.Generator().manual_seed(5 + act)
+    for (M, N, Kd) in [(1280, 3072, 768), (136, 1536, 768), (72, 64, 200)]:
+        a = torch.randn(M, Kd, generator=gen).to(dtype)
+        b = (torch.randn(N, Kd, generator=gen) / math.sqrt(Kd)).to(dtype)
+        bias = torch.randn(N, generator=gen)
+        pre_ref = a.float() @ b.float().t() + bias
+        ref = pre_ref if act == 0 else (F.gelu(pre_ref) if act == 1 else F.relu(pre_ref))
+        out = torch.empty(M, N, dtype=dtype, device=DEV)
+        pre = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm_act(a.to(DEV), b.to(DEV), out, bias.to(DEV), act, pre)
+        _assert_close(out, ref, dtype)
+        _assert_close(pre, pre_ref, dtype)
+        out2 = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm_act(a.to(DEV), b.to(DEV), out2, bias.to(DEV), act, None)
+        assert torch.equal(out2, out)
+
+
+def test_gemm_accumulates_into_bf16_output(K):
+    """dx = dres + dy W: the sum is formed in fp32 and rounded once."""
+    gen = torch.Generator().manual_seed(11)
+    for (M, N, Kd, bkm) in [(1280, 768, 3072, False), (4096, 768, 768, False), (520, 72, 136, True)]:
+        a = torch.randn(M, Kd, generator=gen).bfloat16()
+        b = (torch.randn((N, Kd) if bkm else (Kd, N), generator=gen) / math.sqrt(Kd)).bfloat16()
+        c0 = torch.randn(M, N, generator=gen).bfloat16()
+        ref = c0.float() + a.float() @ (b.float().t() if bkm else b.float())
+        c = c0.to(DEV)
+        K.gemm(a.to(DEV), b.to(DEV), c, None, True, bkm, accumulate=True)
+        assert torch.allclose(c.float().cpu(), ref, rtol=1e-2, atol=1e-2), (c.float().cpu() - ref).abs().max()
+
+
+def test_colsum_finish_multi(K):
+    gen = torch.Generator().manual_seed(3)
+    for (npart, cols, n) in [(1572, 768, 3), (16, 1536, 2), (300, 72, 4), (1, 768, 1)]:
+        parts = [torch.randn(npart, cols, generator=gen).to(DEV) for _ in range(n)]
+        outs = [torch.randn(cols, generator=gen).to(DEV) for _ in range(n)]
+        refs = [o.double().cpu() + p.double().cpu().sum(0) for o, p in zip(outs, parts)]
+        K.colsum_finish_multi(parts, outs)
+        for o, r in zip(outs, refs):
+            assert torch.allclose(o.double().cpu(), r, rtol=1e-5, atol=1e-3)

@@ -35,7 +35,7 @@ if os.environ.get("PROFILE"):
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(28)
+    st.sort_stats("tottime").print_stats(45)
 
 st0 = torch.cuda.memory_stats()
 for i in range(4):
