@@ -71,6 +71,15 @@ template <typename T, bool KMAJ> struct PlainSrc {
             return p + k * ld + c;
         }
     }
+    // split addressing of the 8-phase kernel (contraction-contiguous only): per-lane byte offset of chunk i
+    // (row clamped) + a wave-uniform base for the K offset, so the loads use the scalar-base addressing form
+    __device__ __forceinline__ uint32_t lane_off(int tid, int i, int nthr) const {
+        const int c = tid + nthr * i, w = c % (64 * Tile64<T>::CH);
+        const int t = c / (64 * Tile64<T>::CH), row = w / Tile64<T>::CH, ch = (w % Tile64<T>::CH) ^ (row & 7);
+        const int64_t gr = min(r0 + 64 * t + row, R - 1);
+        return (uint32_t)((gr * ld + ch * Tile64<T>::EPC) * (int64_t)sizeof(T));
+    }
+    __device__ __forceinline__ const char* k_base(int64_t k0) const { return reinterpret_cast<const char*>(p + k0); }
     // always-valid address for a K-step that lies fully inside K: rows / columns beyond R are clamped
     // (they only feed output rows / columns that are never stored)
     __device__ __forceinline__ const T* gaddr(int, int t, int row, int ch, int64_t k0) const {
@@ -118,6 +127,16 @@ template <typename T, int NTHR> struct ConvRowSrc {
         const int tap = (int)(k0 / g.Cin);
         ok = okr[i];
         return x + base[i] + tap_offset(g, tap) + (k0 % g.Cin);
+    }
+    __device__ __forceinline__ uint32_t lane_off(int tid, int i, int nthr) const {
+        const int c = tid + nthr * i, w = c % (64 * Tile64<T>::CH);
+        const int t = c / (64 * Tile64<T>::CH), row = w / Tile64<T>::CH, ch = (w % Tile64<T>::CH) ^ (row & 7);
+        const int64_t m = r0 + 64 * t + row;
+        return (uint32_t)(((int64_t)pos[m < M ? m : 0] * g.Cin + ch * Tile64<T>::EPC) * (int64_t)sizeof(T));
+    }
+    __device__ __forceinline__ const char* k_base(int64_t k0) const {
+        const uint32_t k = (uint32_t)k0, tap = k / (uint32_t)g.Cin;
+        return reinterpret_cast<const char*>(x + tap_offset(g, (int)tap) + (k - tap * (uint32_t)g.Cin));
     }
     __device__ __forceinline__ const T* gaddr(int i, int, int, int, int64_t k0) const {
         const uint32_t k = (uint32_t)k0, tap = k / (uint32_t)g.Cin;   // wave-uniform 32-bit scalar math
@@ -218,11 +237,11 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 template <typename TC> struct RowWriter;
 template <> struct RowWriter<bf16_t> {
     __device__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
-                               int64_t N, int lane) {
+                               int64_t N, int lane, int gap = 0) {
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
             const int row = 8 * p + (lane >> 3), col = (lane & 7) * 8;
-            const int64_t m = mbase + row, n = nbase + col;
+            const int64_t m = mbase + row, n = nbase + col + (col >= 32 ? gap : 0);
             if (m >= M || n >= N) continue;
             const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
             const f32x4 b = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col + 4);
@@ -259,9 +278,9 @@ template <> struct RowWriter<bf16_t> {
 };
 template <> struct RowWriter<float> {
     __device__ static void run(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
-                               int64_t N, int lane) {
+                               int64_t N, int lane, int gap = 0) {
         if (ep.atomic) {                               // one 256-byte row segment per wave instruction
-            const int64_t n = nbase + lane;
+            const int64_t n = nbase + lane + (lane >= 32 ? gap : 0);
             for (int row = 0; row < 64; ++row) {
                 const int64_t m = mbase + row;
                 if (m < M && n < N) atomicAdd(ep.c + m * ep.ldc + n, stage[row * STG_LD + lane]);
@@ -271,7 +290,7 @@ template <> struct RowWriter<float> {
 #pragma unroll 2
         for (int p = 0; p < 16; ++p) {
             const int row = 4 * p + (lane >> 4), col = (lane & 15) * 4;
-            const int64_t m = mbase + row, n = nbase + col;
+            const int64_t m = mbase + row, n = nbase + col + (col >= 32 ? gap : 0);
             if (m >= M || n >= N) continue;
             const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
             float u[4] = {a[0], a[1], a[2], a[3]};
@@ -452,6 +471,226 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves, four phases per K-tile ("8-phase" schedule of the CDNA4 guide):
+// both operands contraction-contiguous (forward GEMMs, conv forward, and dgrad against a transposed
+// weight copy), bf16, K % 64 == 0.
+//   * the K-tile lives in LDS as four half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255), two
+//     K-tiles deep (128 KiB); a wave owns 64 rows of EACH A half and 32 columns of EACH B half, so the
+//     four phases are the (A-half, B-half) quadrants of its 128 x 64 result: 16 MFMAs each;
+//   * every phase issues the LDS reads of its quadrant and ONE half-tile of direct-to-LDS prefetch
+//     (2 wave instructions), then barrier / MFMAs / barrier.  The two wave groups (wr = 0 / 1, the two
+//     waves of each SIMD) run one barrier apart: while one is in its MFMA block the other issues its LDS
+//     reads and loads;
+//   * the prefetch is 7 phases ahead of its first use and is only waited for once per K-tile with a
+//     counted vmcnt (three half-tiles stay in flight across the wait); raw s_barrier, never __syncthreads
+//     (which would drain the loads).
+// Buffer hazards (X = buffer of the K-tile being computed, Y = the other one), per K-tile t:
+//   phase  LDS reads (X)     prefetch                      restage distance after the last read
+//   1      B0 (4), A0 (8)    A1 of t+1 -> Y                A1(Y) was read in phase 3 of t-1: 2 phases
+//   2      B1 (4)            B0 of t+2 -> X                1 phase: phase 1 retires its B reads (lgkmcnt) BEFORE its barrier
+//   3      A1 (8)            A0 of t+2 -> X                2 phases
+//   4      -                 B1 of t+2 -> X, vmcnt(6)      2 phases; the wait retires everything of tile t+1
+// ---------------------------------------------------------------------------------------------
+template <typename TC, typename SrcA, typename SrcB>
+__global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
+                                                    int grid_m) {
+    static_assert(SrcA::KMAJOR && SrcB::KMAJOR, "contraction-contiguous operands only");
+    using T = bf16_t;
+    using TL = Tile64<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = 512;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wr = wave_u >> 2, wc = wave_u & 3;
+    const int64_t n_tiles = (int64_t)gridDim.x, gn_t = n_tiles / grid_m;
+    const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
+    const int64_t tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
+    const int64_t bm = tile / gn_t, bn = tile % gn_t;
+    const int64_t m0 = bm * 256, n0 = bn * 256;
+    sa.r0 = m0;
+    sb.r0 = n0;
+    uint32_t offa[4], offb[4];                       // chunk i = Tile64 i of the operand (rows 64 i ..)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offa[i] = sa.lane_off(tid, i, NTHR);
+        offb[i] = sb.lane_off(tid, i, NTHR);
+    }
+
+    f32x4 acc[2][2][4][2];                           // [A half][B half][16-row block][16-col block]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int STAGE_BYTES = 8 * TL::BYTES;       // A: Tile64 0..3, B: Tile64 4..7
+    constexpr int B_OFF = 4 * TL::BYTES;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int64_t nk = K / BK;
+    // half-tile h of operand A / B of K-tile kt -> buffer buf (no-op past the end of K)
+    auto stage_a = [&](int buf, int h, int64_t kt) {
+        if (kt >= nk) return;
+        const char* kb = sa.k_base(kt * BK);
+        char* base = smem + buf * STAGE_BYTES + 64 * wave_u * 16;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(kb + offa[2 * h + ii]), (lds_ptr)(base + NTHR * (2 * h + ii) * 16), 16, 0, 0);
+    };
+    auto stage_b = [&](int buf, int h, int64_t kt) {
+        if (kt >= nk) return;
+        const char* kb = sb.k_base(kt * BK);
+        char* base = smem + buf * STAGE_BYTES + B_OFF + 64 * wave_u * 16;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(kb + offb[2 * h + ii]), (lds_ptr)(base + NTHR * (2 * h + ii) * 16), 16, 0, 0);
+    };
+
+    // prologue: K-tile 0 completely, K-tile 1 without its A1 (phase 1 issues that)
+    stage_b(0, 0, 0); stage_a(0, 0, 0); stage_b(0, 1, 0); stage_a(0, 1, 0);
+    stage_b(1, 0, 1); stage_a(1, 0, 1); stage_b(1, 1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // second wave group runs one barrier behind
+
+    Frag<T> fa[4][2], fb0[2][2], fb1[2][2];
+    int cur = 0;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const char* X = smem + cur * STAGE_BYTES;
+        const char* tA0 = X + wr * TL::BYTES;                      // this wave's 64 rows of each A half
+        const char* tA1 = X + (2 + wr) * TL::BYTES;
+        const char* tB0 = X + B_OFF + (wc >> 1) * TL::BYTES;       // 32 rows (columns of C) of each B half
+        const char* tB1 = X + B_OFF + (2 + (wc >> 1)) * TL::BYTES;
+        const int brow = (wc & 1) * 32 + li;
+        // ---- phase 1: quadrant (A0, B0)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = lds_row_frag<T>(tB0, brow + 16 * j, 32 * ks, g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_row_frag<T>(tA0, 16 * i + li, 32 * ks, g);
+        stage_a(cur ^ 1, 1, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");         // the four B0 reads have returned: B0 may be restaged
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(acc[0][0][i][j], fb0[j][ks], fa[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: quadrant (A0, B1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = lds_row_frag<T>(tB1, brow + 16 * j, 32 * ks, g);
+        stage_b(cur, 0, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(acc[0][1][i][j], fb1[j][ks], fa[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: quadrant (A1, B1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_row_frag<T>(tA1, 16 * i + li, 32 * ks, g);
+        stage_a(cur, 0, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(acc[1][1][i][j], fb1[j][ks], fa[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 4: quadrant (A1, B0); K-tile t+1 is complete after this wait
+        stage_b(cur, 1, kt + 2);
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(acc[1][0][i][j], fb0[j][ks], fa[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // re-align the wave groups
+    __syncthreads();
+
+    // epilogue: per A half, the wave's 64 rows x (32 + 32) columns staged as one 64 x 64 fp32 piece; the
+    // second 32 columns live 128 further right in C (gap = 96)
+    float* stg = reinterpret_cast<float*>(smem) + wave * (64 * STG_LD);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4*>(stg + (16 * i + li) * STG_LD + 32 * b + 16 * j + 4 * g) = acc[a][b][i][j];
+        __syncthreads();
+        RowWriter<TC>::run(stg, ep, m0 + 128 * a + 64 * wr, n0 + 32 * wc, M, N, lane, 96);
+    }
+}
+
+template <typename TC, typename SrcA, typename SrcB>
+static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what) {
+    const int64_t gm = (M + 255) / 256, gn = (N + 255) / 256;
+    if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
+    const size_t lds = std::max<size_t>(2 * 8 * Tile64<bf16_t>::BYTES, (size_t)8 * 64 * STG_LD * 4);
+    auto kern = gemm8_kernel<TC, SrcA, SrcB>;
+    static bool raised = false;                      // per instantiation
+    if (!raised) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn)), dim3(512), lds, st, sa, sb, ep, M, N, K, (int)gm);
+    return check_launch(what);
+}
+
+// the 8-phase kernel is used for bf16 NT problems with whole K-steps, >= 2 of them, at least `min_tiles`
+// 256 x 256 tiles and operands addressable with 32-bit byte offsets
+static bool use_gemm8(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t bytes_b) {
+    static const int mode = []() { const char* e = getenv("SHG_GEMM8"); return e ? atoi(e) : 1; }();
+    static const int64_t min_tiles = []() { const char* e = getenv("SHG_GEMM8_MIN_TILES"); return e ? (int64_t)atoi(e) : (int64_t)96; }();
+    if (!mode || K % BK || K < 2 * BK) return false;
+    if (bytes_a >= ((int64_t)1 << 32) || bytes_b >= ((int64_t)1 << 32)) return false;
+    return ((M + 255) / 256) * ((N + 255) / 256) >= min_tiles;
+}
+
 template <typename T, typename TC, typename SrcA, typename SrcB, int TM, int TN, int WM, int WN>
 static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
                       bool allow_split) {
@@ -499,6 +738,10 @@ static int gemm_plain(const T* A, const T* B, Epilogue<TC> ep, int64_t M, int64_
     PlainSrc<T, AK> sa{A, lda, 0, M, K};
     PlainSrc<T, BK_> sb{B, ldb, 0, N, K};
     const bool split_ok = !AK && !BK_ && std::is_same<TC, float>::value;
+    if constexpr (std::is_same<T, bf16_t>::value && AK && BK_) {
+        if (use_gemm8(M, N, K, M * lda * 2, N * ldb * 2))
+            return launch8<TC, PlainSrc<T, true>, PlainSrc<T, true>>(sa, sb, ep, M, N, K, st, what);
+    }
     if constexpr (std::is_same<T, bf16_t>::value) {
         if (use_large(1, M, N, K)) return launch_cfg<T, TC, PlainSrc<T, AK>, PlainSrc<T, BK_>, 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, what, split_ok);
     }
@@ -650,6 +893,10 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     }
     PlainSrc<bf16_t, true> sb{(const bf16_t*)w, K, 0, N, K};
     Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre, 0};
+    if (use_gemm8(M, N, K, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2, N * K * 2)) {
+        ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
+        return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
+    }
     if (use_large(1, M, N, K)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
         return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);

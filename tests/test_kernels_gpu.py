@@ -532,3 +532,54 @@ def test_colsum_finish_multi(K):
         K.colsum_finish_multi(parts, outs)
         for o, r in zip(outs, refs):
             assert torch.allclose(o.double().cpu(), r, rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ 8-phase 256 x 256 kernel
+def test_gemm_8phase_kernel_shapes_and_epilogues(K):
+    """bf16, both operands contraction-contiguous, K a multiple of 64 and >= 96 tiles of 256 x 256 take the
+    8-phase kernel (gemm.hip: gemm8_kernel): odd / even numbers of K-tiles, ragged M and N, every epilogue."""
+    for (M, N, Kd) in [(4096, 3072, 128), (4104, 3080, 192), (3592, 3592, 832), (12576, 2304, 768), (6200, 4040, 64 * 7)]:
+        _gemm_case(K, torch.bfloat16, True, True, M, N, Kd, False, torch.bfloat16, with_bias=True)
+        _gemm_case(K, torch.bfloat16, True, True, M, N, Kd, False, torch.float32, with_bias=False)
+    _gemm_case(K, torch.bfloat16, True, True, 4096, 4096, 512, True, torch.float32, with_bias=False)
+    _gemm_case(K, torch.bfloat16, True, True, 4096, 4096, 512, True, torch.bfloat16, with_bias=False)
+    gen = torch.Generator().manual_seed(21)
+    M, N, Kd = 12576, 3072, 768
+    a = torch.randn(M, Kd, generator=gen).bfloat16()
+    b = (torch.randn(N, Kd, generator=gen) / math.sqrt(Kd)).bfloat16()
+    bias = torch.randn(N, generator=gen)
+    pre_ref = a.float() @ b.float().t() + bias
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    K.gemm_act(a.to(DEV), b.to(DEV), out, bias.to(DEV), 1, pre)
+    _assert_close(out, F.gelu(pre_ref), torch.bfloat16)
+    _assert_close(pre, pre_ref, torch.bfloat16)
+
+
+def test_gemm_8phase_kernel_is_exact_and_race_free_on_integer_data(K):
+    """Small-integer operands are exact in bf16 / fp32 accumulation: any stale or early LDS read (the kernel keeps
+    three half-tiles of direct-to-LDS prefetch in flight across its barriers) shows up as a wrong entry.
+    Repeated, with a long contraction, under memory load from a concurrent copy."""
+    M, N, Kd = 4096, 4096, 4096
+    gen = torch.Generator().manual_seed(9)
+    a = torch.randint(-3, 4, (M, Kd), generator=gen).float()
+    b = torch.randint(-2, 3, (N, Kd), generator=gen).float()
+    ref = (a.to(DEV) @ b.to(DEV).t()).cpu()              # fp32 on exact integers: exact
+    aa, bb = a.bfloat16().to(DEV), b.bfloat16().to(DEV)
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    for it in range(6):
+        out = torch.empty(M, N, device=DEV)
+        with torch.cuda.stream(side):
+            big.copy_(big.flip(0)) if it % 2 else big.zero_()
+        K.gemm(aa, bb, out, None, True, True)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref), it
+    # asymmetric layout check on a small K
+    M, N, Kd = 3584, 3584, 128
+    a = (torch.arange(M * Kd).view(M, Kd) % 7 - 3).float()
+    b = (torch.arange(N * Kd).view(N, Kd) % 5 - 2).float()
+    b[3, 5] = 9
+    out = torch.empty(M, N, device=DEV)
+    K.gemm(a.bfloat16().to(DEV), b.bfloat16().to(DEV), out, None, True, True)
+    assert torch.equal(out.cpu(), a @ b.t())
