@@ -71,15 +71,26 @@ template <typename T, bool KMAJ> struct PlainSrc {
             return p + k * ld + c;
         }
     }
-    // split addressing of the 8-phase kernel (contraction-contiguous only): per-lane byte offset of chunk i
-    // (row clamped) + a wave-uniform base for the K offset, so the loads use the scalar-base addressing form
+    // split addressing of the 8-phase kernel: per-lane byte offset of chunk i (row / column clamped into the
+    // matrix) + a wave-uniform base for the K offset
+    static constexpr bool DYN = false;
     __device__ __forceinline__ uint32_t lane_off(int tid, int i, int nthr) const {
+        int t, row, ch;
         const int c = tid + nthr * i, w = c % (64 * Tile64<T>::CH);
-        const int t = c / (64 * Tile64<T>::CH), row = w / Tile64<T>::CH, ch = (w % Tile64<T>::CH) ^ (row & 7);
-        const int64_t gr = min(r0 + 64 * t + row, R - 1);
-        return (uint32_t)((gr * ld + ch * Tile64<T>::EPC) * (int64_t)sizeof(T));
+        t = c / (64 * Tile64<T>::CH);
+        row = w / Tile64<T>::CH;
+        ch = (w % Tile64<T>::CH) ^ Tile64<T>::template swz<KMAJ>(row);
+        if (KMAJ) {
+            const int64_t gr = min(r0 + 64 * t + row, R - 1);
+            return (uint32_t)((gr * ld + ch * Tile64<T>::EPC) * (int64_t)sizeof(T));
+        }
+        int64_t col = r0 + 64 * t + ch * Tile64<T>::EPC;
+        if (col >= R) col = 0;
+        return (uint32_t)((row * ld + col) * (int64_t)sizeof(T));
     }
-    __device__ __forceinline__ const char* k_base(int64_t k0) const { return reinterpret_cast<const char*>(p + k0); }
+    __device__ __forceinline__ const char* k_base(int, int64_t k0) const {
+        return reinterpret_cast<const char*>(KMAJ ? p + k0 : p + k0 * ld);
+    }
     // always-valid address for a K-step that lies fully inside K: rows / columns beyond R are clamped
     // (they only feed output rows / columns that are never stored)
     __device__ __forceinline__ const T* gaddr(int, int t, int row, int ch, int64_t k0) const {
@@ -97,11 +108,16 @@ template <typename T, bool KMAJ> struct PlainSrc {
 
 struct ConvGeom {
     int Cin, Hp, Wp;          // padded input plane
+    uint32_t inv_cin;         // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, inv_cin) for k < 2^32 / Cin
 };
+static ConvGeom conv_geom(int Cin, int Hp, int Wp) { return ConvGeom{Cin, Hp, Wp, (uint32_t)(0x100000000ull / (uint32_t)Cin) + 1u}; }
+// tap < 45 -> (kt, kh, kw) by multiply-shift (exact on that range): the wave-uniform address math of the
+// direct-to-LDS loads sits in the instruction stream of the load phase, where an integer division costs ~30 instructions
 __device__ __forceinline__ int64_t tap_offset(const ConvGeom& g, int tap) {
-    const int kt = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+    const int kt = (tap * 57) >> 9, r = tap - 9 * kt, kh = (r * 11) >> 5, kw = r - 3 * kh;
     return ((int64_t)(kt * g.Hp + kh) * g.Wp + kw) * g.Cin;
 }
+__device__ __forceinline__ uint32_t div_cin(const ConvGeom& g, uint32_t k) { return __umulhi(k, g.inv_cin); }
 
 // A operand of the conv forward: rows = output positions (gathered), K = (tap, channel), K contiguous.
 template <typename T, int NTHR> struct ConvRowSrc {
@@ -128,18 +144,19 @@ template <typename T, int NTHR> struct ConvRowSrc {
         ok = okr[i];
         return x + base[i] + tap_offset(g, tap) + (k0 % g.Cin);
     }
+    static constexpr bool DYN = false;
     __device__ __forceinline__ uint32_t lane_off(int tid, int i, int nthr) const {
         const int c = tid + nthr * i, w = c % (64 * Tile64<T>::CH);
         const int t = c / (64 * Tile64<T>::CH), row = w / Tile64<T>::CH, ch = (w % Tile64<T>::CH) ^ (row & 7);
         const int64_t m = r0 + 64 * t + row;
         return (uint32_t)(((int64_t)pos[m < M ? m : 0] * g.Cin + ch * Tile64<T>::EPC) * (int64_t)sizeof(T));
     }
-    __device__ __forceinline__ const char* k_base(int64_t k0) const {
-        const uint32_t k = (uint32_t)k0, tap = k / (uint32_t)g.Cin;
+    __device__ __forceinline__ const char* k_base(int, int64_t k0) const {
+        const uint32_t k = (uint32_t)k0, tap = div_cin(g, k);
         return reinterpret_cast<const char*>(x + tap_offset(g, (int)tap) + (k - tap * (uint32_t)g.Cin));
     }
     __device__ __forceinline__ const T* gaddr(int i, int, int, int, int64_t k0) const {
-        const uint32_t k = (uint32_t)k0, tap = k / (uint32_t)g.Cin;   // wave-uniform 32-bit scalar math
+        const uint32_t k = (uint32_t)k0, tap = div_cin(g, k);   // wave-uniform 32-bit scalar math
         return x + base[i] + tap_offset(g, (int)tap) + (k - tap * (uint32_t)g.Cin);   // rows beyond M read position 0 (valid)
     }
 };
@@ -170,11 +187,27 @@ template <typename T, int NTHR> struct ConvColSrc {
         const int tap = (int)(c / g.Cin);
         return x + (int64_t)pos[mm] * g.Cin + tap_offset(g, tap) + (c % g.Cin);
     }
+    // 8-phase kernel (512 threads): every chunk of a thread sits in row tid >> 3 of its Tile64, so one gather
+    // position per thread and K-tile serves all of them; the column block (tap, channel base) is wave-uniform.
+    static constexpr bool DYN = true;
+    __device__ __forceinline__ int dyn_row(int tid) const { return tid >> 3; }
+    __device__ __forceinline__ const int32_t* dyn_ptr(int tid, int64_t k0) const { return pos + min(k0 + (tid >> 3), K - 1); }
+    __device__ __forceinline__ uint32_t dyn_off(int tid, int32_t p) const {
+        const int row = tid >> 3, ch = (tid & 7) ^ Tile64<T>::swz_ks(row);
+        return (uint32_t)(((int64_t)p * g.Cin + ch * Tile64<T>::EPC) * (int64_t)sizeof(T));
+    }
+    __device__ __forceinline__ uint32_t lane_off(int, int, int) const { return 0; }
+    __device__ __forceinline__ const char* k_base(int i, int64_t) const {
+        uint32_t cb = (uint32_t)(r0 + 64 * i);
+        if (cb >= (uint32_t)R) cb = 0;
+        const uint32_t tap = div_cin(g, cb), c0 = cb - tap * (uint32_t)g.Cin;
+        return reinterpret_cast<const char*>(x + tap_offset(g, (int)tap) + c0);
+    }
     __device__ __forceinline__ const T* gaddr(int i, int t, int, int ch, int64_t) const {
         // a 64-wide column block never straddles a tap (Cin % 64 == 0): tap and channel base are uniform
         uint32_t cb = (uint32_t)(r0 + 64 * t);
         if (cb >= (uint32_t)R) cb = 0;
-        const uint32_t tap = cb / (uint32_t)g.Cin, c0 = cb - tap * (uint32_t)g.Cin;
+        const uint32_t tap = div_cin(g, cb), c0 = cb - tap * (uint32_t)g.Cin;
         return x + (int64_t)posreg[i] * g.Cin + tap_offset(g, (int)tap) + c0 + ch * Tile64<T>::EPC;
     }
 };
@@ -188,6 +221,7 @@ template <typename T> struct ConvWeightColSrc {
     const T* w;
     int64_t r0, R, K;         // R = Cin (columns), K = 45 * Cout
     int Cin, Cout;
+    uint32_t inv_cout;        // floor(2^32 / Cout) + 1
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void prefetch(int, int64_t) {}
     __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
@@ -199,9 +233,21 @@ template <typename T> struct ConvWeightColSrc {
         const int64_t co = kk % Cout;
         return w + (co * 45 + tapf) * (int64_t)Cin + c;
     }
+    static constexpr bool DYN = false;
+    __device__ __forceinline__ uint32_t lane_off(int tid, int i, int nthr) const {
+        const int c = tid + nthr * i, w_ = c % (64 * Tile64<T>::CH);
+        const int t = c / (64 * Tile64<T>::CH), row = w_ / Tile64<T>::CH, ch = (w_ % Tile64<T>::CH) ^ Tile64<T>::swz_ks(row);
+        int64_t col = r0 + 64 * t + ch * Tile64<T>::EPC;
+        if (col >= R) col = 0;
+        return (uint32_t)(((int64_t)row * 45 * Cin + col) * (int64_t)sizeof(T));
+    }
+    __device__ __forceinline__ const char* k_base(int, int64_t k0) const {
+        const uint32_t k = (uint32_t)k0, tap = __umulhi(k, inv_cout), co0 = k - tap * (uint32_t)Cout;
+        return reinterpret_cast<const char*>(w + ((int64_t)co0 * 45 + (44 - (int)tap)) * (int64_t)Cin);
+    }
     __device__ __forceinline__ const T* gaddr(int, int t, int row, int ch, int64_t k0) const {
         // Cout % 64 == 0: a K-step stays inside one tap
-        const uint32_t k = (uint32_t)k0, tap = k / (uint32_t)Cout, co0 = k - tap * (uint32_t)Cout;
+        const uint32_t k = (uint32_t)k0, tap = __umulhi(k, inv_cout), co0 = k - tap * (uint32_t)Cout;
         int64_t c = r0 + 64 * t + ch * Tile64<T>::EPC;
         if (c >= R) c = 0;
         return w + ((int64_t)(co0 + row) * 45 + (44 - (int)tap)) * (int64_t)Cin + c;
@@ -341,10 +387,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
     // re-read one A row-panel (for the convolution: the gathered activations, re-read once per
     // 128 output channels) run back-to-back on one XCD and hit its L2 instead of the Infinity Cache;
     // the weight panels are small per K-step and stay L2-resident on every XCD.  Bijective for any grid.
-    const int64_t n_tiles = (int64_t)gridDim.x, gn_t = n_tiles / grid_m;
+    // grid_m < 0: walk M fastest instead (few row tiles, many column tiles - the weight-gradient shapes - so
+    // that the tiles sharing a B column-panel sit next to each other)
+    const int64_t n_tiles = (int64_t)gridDim.x, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
     const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
     const int64_t tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
-    const int64_t bm = tile / gn_t, bn = tile % gn_t;
+    const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
     const int64_t m0 = bm * (TM * 64), n0 = bn * (TN * 64);
     sa.r0 = m0;
     sb.r0 = n0;
@@ -493,29 +541,82 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
 //   3      A1 (8)            A0 of t+2 -> X                2 phases
 //   4      -                 B1 of t+2 -> X, vmcnt(6)      2 phases; the wait retires everything of tile t+1
 // ---------------------------------------------------------------------------------------------
+// tile walk inside an XCD's range: the smaller grid dimension fastest (its tiles share the other operand's panel,
+// which then comes out of the XCD's L2 instead of the Infinity Cache); encoded in the sign of grid_m
+static int tile_order(int64_t gm, int64_t gn) {
+    static const int mode = []() { const char* e = getenv("SHG_TILE_ORDER"); return e ? atoi(e) : 0; }();   // 1: N fastest, 2: M fastest
+    const bool m_fast = mode == 2 || (mode == 0 && gm < gn);
+    return m_fast ? -(int)gm : (int)gm;
+}
+
+// Transposing LDS read of a contraction-strided tile as inline assembly: through the builtin the compiler
+// cannot tell the read from the in-flight direct-to-LDS writes and drains them (s_waitcnt vmcnt(0)) before
+// every group of reads, which serialises the prefetch.  The result is only valid after the kernel's own
+// s_waitcnt lgkmcnt + sched_barrier.  The per-lane part of the address (row 8g+q, the XOR-swizzled column
+// chunk) is loop-invariant and kept in a register; K sub-step, row pair and half-tile go into the immediate.
+template <int OFF> __device__ __forceinline__ s16x4 tr_read(uint32_t addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// fragment (natural slot order, as lds_col_frag_nat) of columns col0.. of a Tile64 at byte offset TOFF from `base`,
+// K sub-step KS; `base` = LDS address of the lane's element (row 8g+q, column col0 + 4p) of the first tile
+template <int TOFF, int KS> __device__ __forceinline__ Frag<bf16_t> tr_frag(uint32_t base) {
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = tr_read<TOFF + KS * 32 * 128>(base);
+    u.s[1] = tr_read<TOFF + KS * 32 * 128 + 4 * 128>(base);
+    Frag<bf16_t> f;
+    f.v = u.v;
+    return f;
+}
+__device__ __forceinline__ uint32_t tr_lane_base(const char* tile, int col0, int lane) {
+    typedef __attribute__((address_space(3))) const char* lds_cptr;
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    return (uint32_t)(uintptr_t)(lds_cptr)tile + Tile64<bf16_t>::elem_off_ks(8 * g + q, col0 + 4 * p);
+}
+
 template <typename TC, typename SrcA, typename SrcB>
 __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
                                                     int grid_m) {
-    static_assert(SrcA::KMAJOR && SrcB::KMAJOR, "contraction-contiguous operands only");
+    static_assert(!SrcA::DYN, "only the B operand may gather per K-tile");
     using T = bf16_t;
     using TL = Tile64<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 512;
+    constexpr bool AK = SrcA::KMAJOR, BKM = SrcB::KMAJOR;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wr = wave_u >> 2, wc = wave_u & 3;
-    const int64_t n_tiles = (int64_t)gridDim.x, gn_t = n_tiles / grid_m;
+    // grid_m < 0: walk M fastest instead (few row tiles, many column tiles - the weight-gradient shapes - so
+    // that the tiles sharing a B column-panel sit next to each other)
+    const int64_t n_tiles = (int64_t)gridDim.x, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
     const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
     const int64_t tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
-    const int64_t bm = tile / gn_t, bn = tile % gn_t;
+    const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
     const int64_t m0 = bm * 256, n0 = bn * 256;
     sa.r0 = m0;
     sb.r0 = n0;
-    uint32_t offa[4], offb[4];                       // chunk i = Tile64 i of the operand (rows 64 i ..)
+    // K range of this workgroup (gridDim.y > 1: split-K, partial sums added with atomics by the epilogue)
+    const int64_t nk_all = K / BK;
+    const int64_t per_split = (nk_all + gridDim.y - 1) / gridDim.y;
+    const int64_t kb = (int64_t)blockIdx.y * per_split;
+    const int64_t nk = min(nk_all, kb + per_split) - kb;     // K-tiles of this workgroup, numbered 0 .. nk-1 below
+    if (nk <= 0) return;
+
+    uint32_t offa[4], offb[4];                       // chunk i = Tile64 i of the operand (rows / columns 64 i ..)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         offa[i] = sa.lane_off(tid, i, NTHR);
         offb[i] = sb.lane_off(tid, i, NTHR);
+    }
+    // gathered B operand (conv weight gradient): one position per thread and K-tile, fetched three K-tiles ahead
+    // with a load the compiler does not track (it would drain the direct-to-LDS prefetch at the first use) and
+    // retired by the kernel's own counted wait
+    int32_t dpos[3] = {0, 0, 0}, dnext = 0;
+    uint32_t dyn_cur = 0;
+    if constexpr (SrcB::DYN) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) dpos[u] = *sb.dyn_ptr(tid, (kb + u) * BK);
     }
 
     f32x4 acc[2][2][4][2];                           // [A half][B half][16-row block][16-col block]
@@ -532,119 +633,135 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
     constexpr int B_OFF = 4 * TL::BYTES;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
-    const int64_t nk = K / BK;
-    // half-tile h of operand A / B of K-tile kt -> buffer buf (no-op past the end of K)
+    // half-tile h of operand A / B of K-tile kt -> buffer buf (no-op past the end of the K range)
     auto stage_a = [&](int buf, int h, int64_t kt) {
         if (kt >= nk) return;
-        const char* kb = sa.k_base(kt * BK);
         char* base = smem + buf * STAGE_BYTES + 64 * wave_u * 16;
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-            __builtin_amdgcn_global_load_lds((glb_ptr)(kb + offa[2 * h + ii]), (lds_ptr)(base + NTHR * (2 * h + ii) * 16), 16, 0, 0);
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * h + ii;
+            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(i, (kb + kt) * BK) + offa[i]), (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
+        }
     };
-    auto stage_b = [&](int buf, int h, int64_t kt) {
+    auto stage_b = [&](int buf, int h, int64_t kt, uint32_t dyn) {
         if (kt >= nk) return;
-        const char* kb = sb.k_base(kt * BK);
         char* base = smem + buf * STAGE_BYTES + B_OFF + 64 * wave_u * 16;
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-            __builtin_amdgcn_global_load_lds((glb_ptr)(kb + offb[2 * h + ii]), (lds_ptr)(base + NTHR * (2 * h + ii) * 16), 16, 0, 0);
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * h + ii;
+            const uint32_t off = SrcB::DYN ? dyn : offb[i];
+            __builtin_amdgcn_global_load_lds((glb_ptr)(sb.k_base(i, (kb + kt) * BK) + off), (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
+        }
     };
 
     // prologue: K-tile 0 completely, K-tile 1 without its A1 (phase 1 issues that)
-    stage_b(0, 0, 0); stage_a(0, 0, 0); stage_b(0, 1, 0); stage_a(0, 1, 0);
-    stage_b(1, 0, 1); stage_a(1, 0, 1); stage_b(1, 1, 1);
+    {
+        uint32_t d0 = 0, d1 = 0;
+        if constexpr (SrcB::DYN) { d0 = sb.dyn_off(tid, dpos[0]); d1 = sb.dyn_off(tid, dpos[1]); dyn_cur = sb.dyn_off(tid, dpos[2]); }
+        stage_b(0, 0, 0, d0); stage_a(0, 0, 0); stage_b(0, 1, 0, d0); stage_a(0, 1, 0);
+        stage_b(1, 0, 1, d1); stage_a(1, 0, 1); stage_b(1, 1, 1, d1);
+    }
     if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // second wave group runs one barrier behind
 
     Frag<T> fa[4][2], fb0[2][2], fb1[2][2];
+    // contraction-strided operands: per-lane LDS addresses of the wave's column blocks in buffer 0, half 0
+    uint32_t tra[4] = {0, 0, 0, 0}, trb[2] = {0, 0};
+    if constexpr (!AK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tra[i] = tr_lane_base(smem + wr * TL::BYTES, 16 * i, lane);
+    }
+    if constexpr (!BKM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) trb[j] = tr_lane_base(smem + B_OFF + (wc >> 1) * TL::BYTES, (wc & 1) * 32 + 16 * j, lane);
+    }
+#define SHG_G8_RA(H)                                                                                              \
+    if constexpr (AK) {                                                                                           \
+        const char* t_ = X + (2 * (H) + wr) * TL::BYTES;                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_row_frag<T>(t_, 16 * i + li, 32 * ks, g); \
+    } else {                                                                                                      \
+        fa[0][0] = tr_frag<(H) * 2 * TL::BYTES, 0>(tra[0] + xoff); fa[0][1] = tr_frag<(H) * 2 * TL::BYTES, 1>(tra[0] + xoff); \
+        fa[1][0] = tr_frag<(H) * 2 * TL::BYTES, 0>(tra[1] + xoff); fa[1][1] = tr_frag<(H) * 2 * TL::BYTES, 1>(tra[1] + xoff); \
+        fa[2][0] = tr_frag<(H) * 2 * TL::BYTES, 0>(tra[2] + xoff); fa[2][1] = tr_frag<(H) * 2 * TL::BYTES, 1>(tra[2] + xoff); \
+        fa[3][0] = tr_frag<(H) * 2 * TL::BYTES, 0>(tra[3] + xoff); fa[3][1] = tr_frag<(H) * 2 * TL::BYTES, 1>(tra[3] + xoff); \
+    }
+#define SHG_G8_RB(H, FB)                                                                                          \
+    if constexpr (BKM) {                                                                                          \
+        const char* t_ = X + B_OFF + (2 * (H) + (wc >> 1)) * TL::BYTES;                                           \
+        const int c0_ = (wc & 1) * 32;                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) FB[j][ks] = lds_row_frag<T>(t_, c0_ + 16 * j + li, 32 * ks, g); \
+    } else {                                                                                                      \
+        FB[0][0] = tr_frag<(H) * 2 * TL::BYTES, 0>(trb[0] + xoff); FB[0][1] = tr_frag<(H) * 2 * TL::BYTES, 1>(trb[0] + xoff); \
+        FB[1][0] = tr_frag<(H) * 2 * TL::BYTES, 0>(trb[1] + xoff); FB[1][1] = tr_frag<(H) * 2 * TL::BYTES, 1>(trb[1] + xoff); \
+    }
+#define SHG_G8_MMA(AH, BH, FB)                                               \
+    __builtin_amdgcn_s_setprio(1);                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) mma(acc[AH][BH][i][j], FB[j][ks], fa[i][ks]); \
+    __builtin_amdgcn_s_setprio(0);
+
     int cur = 0;
     for (int64_t kt = 0; kt < nk; ++kt) {
         const char* X = smem + cur * STAGE_BYTES;
-        const char* tA0 = X + wr * TL::BYTES;                      // this wave's 64 rows of each A half
-        const char* tA1 = X + (2 + wr) * TL::BYTES;
-        const char* tB0 = X + B_OFF + (wc >> 1) * TL::BYTES;       // 32 rows (columns of C) of each B half
-        const char* tB1 = X + B_OFF + (2 + (wc >> 1)) * TL::BYTES;
-        const int brow = (wc & 1) * 32 + li;
+        const uint32_t xoff = (uint32_t)cur * STAGE_BYTES;
         // ---- phase 1: quadrant (A0, B0)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = lds_row_frag<T>(tB0, brow + 16 * j, 32 * ks, g);
+        if constexpr (SrcB::DYN) {
+            if (kt + 3 < nk)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dnext) : "v"(sb.dyn_ptr(tid, (kb + kt + 3) * BK)) : "memory");
+        }
+        SHG_G8_RB(0, fb0)
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_row_frag<T>(tA0, 16 * i + li, 32 * ks, g);
+        SHG_G8_RA(0)
         stage_a(cur ^ 1, 1, kt + 1);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");         // the four B0 reads have returned: B0 may be restaged
+        // the B0 reads (issued first) have returned: B0 may be restaged by the other wave group after the barrier
+        if constexpr (AK) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(acc[0][0][i][j], fb0[j][ks], fa[i][ks]);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);           // register-only MFMAs would otherwise be hoisted above the wait
+        SHG_G8_MMA(0, 0, fb0)
         __builtin_amdgcn_s_barrier();
         // ---- phase 2: quadrant (A0, B1)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = lds_row_frag<T>(tB1, brow + 16 * j, 32 * ks, g);
-        stage_b(cur, 0, kt + 2);
+        SHG_G8_RB(1, fb1)
+        stage_b(cur, 0, kt + 2, dyn_cur);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(acc[0][1][i][j], fb1[j][ks], fa[i][ks]);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);           // register-only MFMAs would otherwise be hoisted above the wait
+        SHG_G8_MMA(0, 1, fb1)
         __builtin_amdgcn_s_barrier();
         // ---- phase 3: quadrant (A1, B1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_row_frag<T>(tA1, 16 * i + li, 32 * ks, g);
+        SHG_G8_RA(1)
         stage_a(cur, 0, kt + 2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(acc[1][1][i][j], fb1[j][ks], fa[i][ks]);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);           // register-only MFMAs would otherwise be hoisted above the wait
+        SHG_G8_MMA(1, 1, fb1)
         __builtin_amdgcn_s_barrier();
         // ---- phase 4: quadrant (A1, B0); K-tile t+1 is complete after this wait
-        stage_b(cur, 1, kt + 2);
+        stage_b(cur, 1, kt + 2, dyn_cur);
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (SrcB::DYN) {                    // the position fetched in phase 1 has landed (older than the 6)
+            asm volatile("" : "+v"(dnext));
+            dyn_cur = sb.dyn_off(tid, dnext);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(acc[1][0][i][j], fb0[j][ks], fa[i][ks]);
-        __builtin_amdgcn_s_setprio(0);
+        SHG_G8_MMA(1, 0, fb0)
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
+#undef SHG_G8_MMA
+#undef SHG_G8_RA
+#undef SHG_G8_RB
     if (wr == 0) __builtin_amdgcn_s_barrier();      // re-align the wave groups
     __syncthreads();
 
@@ -667,7 +784,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
 }
 
 template <typename TC, typename SrcA, typename SrcB>
-static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what) {
+static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
+                   int split = 1) {
     const int64_t gm = (M + 255) / 256, gn = (N + 255) / 256;
     if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
     const size_t lds = std::max<size_t>(2 * 8 * Tile64<bf16_t>::BYTES, (size_t)8 * 64 * STG_LD * 4);
@@ -677,11 +795,13 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn)), dim3(512), lds, st, sa, sb, ep, M, N, K, (int)gm);
+    if (split > 1) ep.atomic = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn), split), dim3(512), lds, st, sa, sb, ep, M, N, K,
+                       tile_order(gm, gn));
     return check_launch(what);
 }
 
-// the 8-phase kernel is used for bf16 NT problems with whole K-steps, >= 2 of them, at least `min_tiles`
+// the 8-phase kernel is used for bf16 problems with whole K-steps, >= 2 of them, at least `min_tiles`
 // 256 x 256 tiles and operands addressable with 32-bit byte offsets
 static bool use_gemm8(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t bytes_b) {
     static const int mode = []() { const char* e = getenv("SHG_GEMM8"); return e ? atoi(e) : 1; }();
@@ -719,7 +839,7 @@ static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, i
             raised = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn), split), dim3(NTHR), lds, st, sa, sb, ep, M, N, K, (int)gm);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn), split), dim3(NTHR), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn));
     return check_launch(what);
 }
 
@@ -738,9 +858,9 @@ static int gemm_plain(const T* A, const T* B, Epilogue<TC> ep, int64_t M, int64_
     PlainSrc<T, AK> sa{A, lda, 0, M, K};
     PlainSrc<T, BK_> sb{B, ldb, 0, N, K};
     const bool split_ok = !AK && !BK_ && std::is_same<TC, float>::value;
-    if constexpr (std::is_same<T, bf16_t>::value && AK && BK_) {
-        if (use_gemm8(M, N, K, M * lda * 2, N * ldb * 2))
-            return launch8<TC, PlainSrc<T, true>, PlainSrc<T, true>>(sa, sb, ep, M, N, K, st, what);
+    if constexpr (std::is_same<T, bf16_t>::value && AK) {          // forward (NT) and input-gradient (NN) forms
+        if (use_gemm8(M, N, K, M * lda * 2, (BK_ ? N : (int64_t)64) * ldb * 2))
+            return launch8<TC, PlainSrc<T, true>, PlainSrc<T, BK_>>(sa, sb, ep, M, N, K, st, what);
     }
     if constexpr (std::is_same<T, bf16_t>::value) {
         if (use_large(1, M, N, K)) return launch_cfg<T, TC, PlainSrc<T, AK>, PlainSrc<T, BK_>, 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, what, split_ok);
@@ -883,7 +1003,7 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     const int64_t M = (int64_t)B * (T - 4) * H * W, N = Cout, K = (int64_t)45 * Cin;
     const int32_t* pos_in = (const int32_t*)workspace;
     const int32_t* pos_out = (const int32_t*)((const char*)workspace + shg_conv3d_k533_workspace_bytes(B, T, H, W) / 2);
-    ConvGeom g{Cin, H + 2, W + 2};
+    ConvGeom g = conv_geom(Cin, H + 2, W + 2);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SHG_F32) {
         ConvRowSrc<float, 256> sa{(const float*)x, pos_in, 0, M, g};
@@ -913,7 +1033,7 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
     // dW[co][(tap, ci)] = sum_m dY[m][co] * Xgather[m][(tap, ci)] : GEMM with M' = Cout, N' = 45*Cin, K' = M
     const int64_t Mo = (int64_t)B * (T - 4) * H * W, Ncols = (int64_t)45 * Cin;
     const int32_t* pos_in = (const int32_t*)workspace;
-    ConvGeom g{Cin, H + 2, W + 2};
+    ConvGeom g = conv_geom(Cin, H + 2, W + 2);
     hipStream_t st = (hipStream_t)stream;
     Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1, nullptr, 0};
     if (dtype == SHG_F32) {
@@ -922,6 +1042,10 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
         return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
     }
     PlainSrc<bf16_t, false> sa{(const bf16_t*)dy, Cout, 0, Cout, Mo};
+    if (use_gemm8(Cout, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
+        ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
+        return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+    }
     if (use_large(1, Cout, Ncols, Mo)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
         return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
@@ -940,16 +1064,20 @@ extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void*
     if (!al16(dy_padded) || !al16(w) || !al16(dx)) return fail_arg("conv3d_dgrad: pointers must be 16-byte aligned");
     const int64_t M = (int64_t)B * (Tp - 4) * H * W, N = Cin, K = (int64_t)45 * Cout;
     const int32_t* pos_in = (const int32_t*)workspace;
-    ConvGeom g{Cout, H + 2, W + 2};
+    ConvGeom g = conv_geom(Cout, H + 2, W + 2);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SHG_F32) {
         ConvRowSrc<float, 256> sa{(const float*)dy_padded, pos_in, 0, M, g};
-        ConvWeightColSrc<float> sb{(const float*)w, 0, N, K, Cin, Cout};
+        ConvWeightColSrc<float> sb{(const float*)w, 0, N, K, Cin, Cout, (uint32_t)(0x100000000ull / (uint32_t)Cout) + 1u};
         Epilogue<float> ep{(float*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
         return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad", false);
     }
-    ConvWeightColSrc<bf16_t> sb{(const bf16_t*)w, 0, N, K, Cin, Cout};
+    ConvWeightColSrc<bf16_t> sb{(const bf16_t*)w, 0, N, K, Cin, Cout, (uint32_t)(0x100000000ull / (uint32_t)Cout) + 1u};
     Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
+    if (Cout % 64 == 0 && use_gemm8(M, N, K, (int64_t)B * Tp * (H + 2) * (W + 2) * Cout * 2, (int64_t)64 * 45 * Cin * 2)) {
+        ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
+        return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
+    }
     if (use_large(1, M, N, K)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
         return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad", false);

@@ -31,3 +31,21 @@ print("  conv1 fwd B=32            %8.1f us %6.0f TF" % (t, 2.0 * B * 12 * 49 * 
 w2 = (torch.randn(768, 5, 3, 3, 768, device=dev) * 0.01).bfloat16()
 t = bench(lambda: K.conv3d_k533_fwd(y1, w2, b1, 1, pad_out=False, want_pre=True), iters=5)
 print("  conv2 fwd B=32            %8.1f us %6.0f TF" % (t, 2.0 * B * 8 * 49 * 768 * 45 * 768 / t / 1e6), flush=True)
+
+for (M, N, Kd) in [(12576, 768, 3072), (12576, 768, 2304), (12576, 3072, 768), (12576, 768, 768)]:
+    dy = torch.randn(M, Kd, device=dev).bfloat16()
+    w = torch.randn(Kd, N, device=dev).bfloat16()
+    dx = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    t = bench(lambda: K.gemm(dy, w, dx, None, True, False))
+    print("  dgrad NN M=%6d N=%5d K=%6d  %8.1f us %6.0f TF" % (M, N, Kd, t, 2.0 * M * N * Kd / t / 1e6), flush=True)
+d1 = torch.randn(B, 12, 7, 7, 768, device=dev).bfloat16()
+dw1 = torch.zeros(768, 5, 3, 3, 2048, device=dev)
+t = bench(lambda: K.conv3d_k533_wgrad(x_cl, d1, dw1, accumulate=True), iters=5)
+print("  conv1 wgrad B=32          %8.1f us %6.0f TF" % (t, 2.0 * B * 12 * 49 * 768 * 45 * 2048 / t / 1e6), flush=True)
+d2 = torch.randn(B, 8, 7, 7, 768, device=dev).bfloat16()
+dw2 = torch.zeros(768, 5, 3, 3, 768, device=dev)
+t = bench(lambda: K.conv3d_k533_wgrad(y1, d2, dw2, accumulate=True), iters=5)
+print("  conv2 wgrad B=32          %8.1f us %6.0f TF" % (t, 2.0 * B * 8 * 49 * 768 * 45 * 768 / t / 1e6), flush=True)
+d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
+t = bench(lambda: K.conv3d_k533_dgrad(d2p, w2), iters=5)
+print("  conv2 dgrad B=32          %8.1f us %6.0f TF" % (t, 2.0 * B * 12 * 49 * 768 * 45 * 768 / t / 1e6), flush=True)
