@@ -188,6 +188,13 @@ int shg_gemm_act(const void* a, const void* b, void* c, const float* bias, int d
                  int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, int act,
                  void* pre, void* stream);
 
+/* Input gradient through Linear + activation in one kernel:  dx[M,N] = (dy[M,K] . W[K,N]) * act'(pre[M,N]) and
+ * dbias[n] += sum_m dx[m,n] (fp32 atomics; dbias may be null).  dy row stride lda, W stored [K, N] with row stride
+ * ldb (the forward weight of the FOLLOWING Linear, [out = K, in = N]), pre contiguous [M, N]: the backward of
+ * BertIntermediate's GELU (modeling_capsbert.py:472-475) folded into BertOutput.dense's input-gradient GEMM. */
+int shg_gemm_dact(const void* dy, const void* w, void* dx, const void* pre, float* dbias, int dtype, int64_t M, int64_t N,
+                  int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Conv3d with kernel (5,3,3), "valid" in T, zero padding 1 in H and W, as an implicit GEMM over a
  * channels-last input.  Replaces ZeroPad2d(1) -> nn.Conv3d(k=(5,3,3)) -> GeLU of

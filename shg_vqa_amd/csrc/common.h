@@ -108,4 +108,27 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// bf16 storage: the same functions with erf from the Abramowitz-Stegun 7.1.26 rational form (|error| <= 1.5e-7, far
+// below the 2^-9 rounding of the stored result).  libm's erff costs ~3x the instructions, and the activation passes over
+// [rows, 3072] are instruction-bound, not HBM-bound, with it.  One exponential serves the cdf AND the density of the
+// gradient; the negative branch uses 1 + erf(x) = poly * exp(-x^2/2) directly (no cancellation in the tail).
+__device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    e = __expf(-0.5f * x * x);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float half_tail = 0.5f * poly * e;              // = 0.5 * erfc(|x| / sqrt 2)
+    cdf = x >= 0.f ? 1.0f - half_tail : half_tail;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float cdf, e;
+    gelu_fast_parts(x, cdf, e);
+    return x * cdf;
+}
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+    float cdf, e;
+    gelu_fast_parts(x, cdf, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 }  // namespace shg

@@ -267,13 +267,23 @@ template <typename TC> struct Epilogue {
     int vec_ok;               // ldc and base pointer allow vector stores of 4 elements
     TC* pre;                  // optional second output [M, N] (ld = N): the value BEFORE the activation
     int atomic;               // split-K: fp32 atomic adds into C (C must hold the running sum already)
+    // activation backward fused into an input-gradient GEMM: C = (A . B) * act'(gpre[m, n]) with gpre [M, N]
+    // (ld = N) the saved pre-activation, and csum[n] += sum_m C[m, n] (the bias gradient), by atomics
+    const TC* gpre;
+    float* csum;
 };
+
+__device__ __forceinline__ float act_grad_rt(float u, int act, bool fast) {
+    if (act == SHG_ACT_GELU) return fast ? gelu_fast_grad(u) : gelu_erf_grad(u);
+    if (act == SHG_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
 
 constexpr int STG_LD = 68;                         // fp32 row stride of the epilogue staging tile (64 + 4 pad)
 constexpr int STG_BYTES = 4 * 64 * STG_LD * 4;     // one 64 x 64 staging tile per wave
 
-__device__ __forceinline__ float apply_act(float x, int act) {
-    if (act == SHG_ACT_GELU) return gelu_erf(x);
+template <bool FAST = false> __device__ __forceinline__ float apply_act(float x, int act) {
+    if (act == SHG_ACT_GELU) return FAST ? gelu_fast(x) : gelu_erf(x);
     if (act == SHG_ACT_RELU) return fmaxf(x, 0.f);
     return x;
 }
@@ -284,6 +294,7 @@ template <typename TC> struct RowWriter;
 template <> struct RowWriter<bf16_t> {
     __device__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0) {
+        float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
             const int row = 8 * p + (lane >> 3), col = (lane & 7) * 8;
@@ -298,15 +309,27 @@ template <> struct RowWriter<bf16_t> {
             const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
             bf16_t* dst = ep.c + crow * ep.ldc + n;
             bf16_t* pre = ep.pre ? ep.pre + m * N + n : nullptr;
+            if (ep.gpre) {                               // (nv == 8: N % 8 == 0 is checked on the host)
+                const bf16x8 gp = *reinterpret_cast<const bf16x8*>(ep.gpre + m * N + n);
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    u[r] *= act_grad_rt((float)gp[r], ep.act, true);
+                    o[r] = (bf16_t)u[r];
+                    csum8[r] += (float)o[r];
+                }
+                *reinterpret_cast<bf16x8*>(dst) = o;
+                continue;
+            }
             if (nv == 8 && ep.vec_ok) {
                 bf16x8 o, q;
                 if (ep.accumulate) {                       // C += A.B in fp32, rounded once (residual-gradient sums)
                     const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(apply_act(u[r], ep.act) + (float)old[r]);
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(apply_act<true>(u[r], ep.act) + (float)old[r]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)apply_act(u[r], ep.act);
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)apply_act<true>(u[r], ep.act);
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) q[r] = (bf16_t)u[r];
@@ -314,11 +337,26 @@ template <> struct RowWriter<bf16_t> {
                 if (pre) *reinterpret_cast<bf16x8*>(pre) = q;
             } else {
                 for (int r = 0; r < nv; ++r) {
-                    const float x = apply_act(u[r], ep.act);
+                    const float x = apply_act<true>(u[r], ep.act);
                     dst[r] = (bf16_t)(ep.accumulate ? x + (float)dst[r] : x);
                     if (pre) pre[r] = (bf16_t)u[r];
                 }
             }
+        }
+        if (ep.csum) {                                   // lanes l, l+8, .. l+56 hold the same 8 columns
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float v = csum8[r];
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                csum8[r] = v;
+            }
+            const int col = (lane & 7) * 8;
+            const int64_t n = nbase + col + (col >= 32 ? gap : 0);
+            if (lane < 8)
+                for (int r = 0; r < 8; ++r)
+                    if (n + r < N) atomicAdd(ep.csum + n + r, csum8[r]);
         }
     }
 };
@@ -333,6 +371,7 @@ template <> struct RowWriter<float> {
             }
             return;
         }
+        float csum4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int p = 0; p < 16; ++p) {
             const int row = 4 * p + (lane >> 4), col = (lane & 15) * 4;
@@ -346,6 +385,16 @@ template <> struct RowWriter<float> {
             const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
             float* dst = ep.c + crow * ep.ldc + n;
             float* pre = ep.pre ? ep.pre + m * N + n : nullptr;
+            if (ep.gpre) {                               // (N % 8 == 0 is checked on the host)
+                const f32x4 gp = *reinterpret_cast<const f32x4*>(ep.gpre + m * N + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u[r] *= act_grad_rt(gp[r], ep.act, false);
+                    csum4[r] += u[r];
+                }
+                *reinterpret_cast<f32x4*>(dst) = f32x4{u[0], u[1], u[2], u[3]};
+                continue;
+            }
             if (nv == 4 && ep.vec_ok) {
                 f32x4 o = {apply_act(u[0], ep.act), apply_act(u[1], ep.act), apply_act(u[2], ep.act), apply_act(u[3], ep.act)};
                 if (ep.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
@@ -358,6 +407,17 @@ template <> struct RowWriter<float> {
                     dst[r] = ep.accumulate ? dst[r] + x : x;
                     if (pre) pre[r] = u[r];
                 }
+            }
+        }
+        if (ep.csum) {                                   // lanes l, l+16, l+32, l+48 hold the same 4 columns
+            const int col = (lane & 15) * 4;
+            const int64_t n = nbase + col + (col >= 32 ? gap : 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = csum4[r];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 16 && n + r < N) atomicAdd(ep.csum + n + r, v);
             }
         }
     }
@@ -961,6 +1021,25 @@ extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias
                         int accumulate, void* stream) {
     return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, SHG_ACT_NONE,
                       nullptr, stream);
+}
+
+extern "C" int shg_gemm_dact(const void* dy, const void* w, void* dx, const void* pre, float* dbias, int dtype, int64_t M,
+                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, void* stream) {
+    if (!dy || !w || !dx || !pre) return fail_arg("gemm_dact: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm_dact: sizes must be positive");
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("gemm_dact: bad dtype");
+    if (act < 0 || act > 2) return fail_arg("gemm_dact: bad activation");
+    const int epc = dtype == SHG_BF16 ? 8 : 4;
+    if (N % 8 || K % epc) return fail_arg("gemm_dact: N must be a multiple of 8 and K of the 16-byte chunk");
+    if (!al16(dy) || !al16(w) || !al16(dx) || !al16(pre)) return fail_arg("gemm_dact: pointers must be 16-byte aligned");
+    if (lda % epc || ldb % epc || ldc % epc || lda < K || ldb < N || ldc < N) return fail_arg("gemm_dact: bad leading dimension");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) {
+        Epilogue<float> ep{(float*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const float*)pre, dbias};
+        return gemm_dispatch<float, float>(dy, w, ep, M, N, K, lda, ldb, 1, 0, st);
+    }
+    Epilogue<bf16_t> ep{(bf16_t*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const bf16_t*)pre, dbias};
+    return gemm_dispatch<bf16_t, bf16_t>(dy, w, ep, M, N, K, lda, ldb, 1, 0, st);
 }
 
 extern "C" int shg_gemm_act(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,

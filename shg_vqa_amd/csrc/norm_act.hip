@@ -19,13 +19,14 @@ __host__ inline int colsum_partials(int64_t rows) {
     return (int)n;
 }
 
-template <int ACT> __device__ __forceinline__ float act_fwd(float u) {
-    if (ACT == SHG_ACT_GELU) return gelu_erf(u);
+// FAST: bf16 storage (gelu_fast, common.h); the fp32 parity mode keeps libm's erff
+template <int ACT, bool FAST> __device__ __forceinline__ float act_fwd(float u) {
+    if (ACT == SHG_ACT_GELU) return FAST ? gelu_fast(u) : gelu_erf(u);
     if (ACT == SHG_ACT_RELU) return fmaxf(u, 0.f);
     return u;
 }
-template <int ACT> __device__ __forceinline__ float act_grad(float u) {
-    if (ACT == SHG_ACT_GELU) return gelu_erf_grad(u);
+template <int ACT, bool FAST> __device__ __forceinline__ float act_grad(float u) {
+    if (ACT == SHG_ACT_GELU) return FAST ? gelu_fast_grad(u) : gelu_erf_grad(u);
     if (ACT == SHG_ACT_RELU) return u > 0.f ? 1.f : 0.f;
     return 1.f;
 }
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float u = xv.get(j) + (bias ? bias[c0 + j] : 0.f);
-                u = act_fwd<ACT>(u);
+                u = act_fwd<ACT, (sizeof(T) == 2)>(u);
                 if (drop_thr) u = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? u * drop_scale : 0.f;
                 if (residual) u += rv.get(j);
                 zv[i][j] = u;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     dzv.set(j, dz);
                     float d = dz;
                     if (drop_thr) d = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? d * drop_scale : 0.f;
-                    if (ACT != SHG_ACT_NONE) d *= act_grad<ACT>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+                    if (ACT != SHG_ACT_NONE) d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
                     dxv.set(j, d);
                     abias[i][j] += to_f32(from_f32<T>(d));
                 }
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__
         Vec16<T> xv = load16(x + off), yv;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float u = act_fwd<ACT>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+            float u = act_fwd<ACT, (sizeof(T) == 2)>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
             if (drop_thr) u = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? u * drop_scale : 0.f;
             yv.set(j, u);
         }
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
                 for (int j = 0; j < V; ++j) {
                     float d = gv.get(j);
                     if (drop_thr) d = dropout_keep(seed, (uint64_t)off + j, drop_thr) ? d * drop_scale : 0.f;
-                    d *= act_grad<ACT>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+                    d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
                     dv.set(j, d);
                     ab[i][j] += to_f32(from_f32<T>(d));
                 }

@@ -303,6 +303,21 @@ def gemm_act(a, b, out, bias, act, pre=None):
     return out
 
 
+def gemm_dact(dy, w, dx, pre, dbias, act):
+    """dx = (dy . w) * act'(pre), dbias += column sums of dx.  dy [M,K]; w [K,N] (a forward weight [out, in]);
+    pre / dx [M,N]; dbias fp32 [N] or None."""
+    _dev(dy, w, dx, pre, dbias)
+    m, k = dy.shape
+    n = w.shape[1]
+    _need(w.shape[0] == k and dx.shape == (m, n) and pre.shape == (m, n), "gemm_dact: shape mismatch")
+    _need(dy.dtype == w.dtype == dx.dtype == pre.dtype, "gemm_dact: one dtype for all operands")
+    _need(dy.stride(1) == 1 and w.stride(1) == 1 and dx.stride(1) == 1 and pre.is_contiguous(), "gemm_dact: layout")
+    _f32vec(dbias, n, "dbias")
+    _lib.call("shg_gemm_dact", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), pre.data_ptr(), _p(dbias), _dt(dy), m, n, k,
+              dy.stride(0), w.stride(0), dx.stride(0), int(act), _stream())
+    return dx
+
+
 def gemm(a, b, out, bias=None, a_kmajor=True, b_kmajor=True, accumulate=False):
     """out[M,N] (+)= A . B (+ bias).  a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N].
     2-D tensors with unit inner stride (row stride = leading dimension)."""

@@ -802,13 +802,18 @@ class _FFNSublayer(torch.autograd.Function):
                                           ACT_NONE, po, seed_o, sid_o, want_dx=True, want_dres=True, want_dbias=want_b2)
         _finish_ln_grads(dg, db, dbi, P.gamma, P.beta, P.b2)
         _wgrad(dt_, h, P.w2, None)
-        dh = torch.empty_like(h)
-        K.gemm(dt_, E.operand(P.w2), dh, None, True, False)
         want_b1 = P.b1._shg_grad is not None
-        dpre, part = K.bias_act_bwd(pre, None if fused else P.b1._shg_store.view(-1), dh, P.act, pi, seed_i, sid_i,
-                                    want_dbias=want_b1)
-        if want_b1:
-            _acc_vec(part, P.b1)
+        if fused:                                   # activation backward + bias gradient in the dgrad GEMM's epilogue
+            dpre = torch.empty_like(h)
+            K.gemm_dact(dt_, E.operand(P.w2), dpre, pre, P.b1._shg_grad.view(-1) if want_b1 else None, P.act)
+            if want_b1:
+                E.grad_written(P.b1)
+        else:
+            dh = torch.empty_like(h)
+            K.gemm(dt_, E.operand(P.w2), dh, None, True, False)
+            dpre, part = K.bias_act_bwd(pre, P.b1._shg_store.view(-1), dh, P.act, pi, seed_i, sid_i, want_dbias=want_b1)
+            if want_b1:
+                _acc_vec(part, P.b1)
         _wgrad(dpre, x2, P.w1, None)
         if not ctx.needs_input_grad[0]:
             return None, None, None

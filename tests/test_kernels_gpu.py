@@ -596,3 +596,43 @@ def test_gemm_8phase_kernel_is_exact_and_race_free_on_integer_data(K):
     out = torch.empty(M, N, device=DEV)
     K.gemm(a.bfloat16().to(DEV), b.bfloat16().to(DEV), out, None, True, True)
     assert torch.equal(out.cpu(), a @ b.t())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [1, 2])
+def test_gemm_dact_fuses_activation_backward_and_bias_gradient(K, dtype, act):
+    gen = torch.Generator().manual_seed(31 + act)
+    for (M, N, Kd) in [(1280, 3072, 768), (12576, 3072, 768), (200, 264, 72)]:
+        if dtype == torch.float32 and M > 5000:
+            continue
+        dy = torch.randn(M, Kd, generator=gen).to(dtype)
+        w = (torch.randn(Kd, N, generator=gen) / math.sqrt(Kd)).to(dtype)
+        pre = torch.randn(M, N, generator=gen).to(dtype)
+        p32 = pre.float().requires_grad_(True)
+        (F.gelu(p32) if act == 1 else F.relu(p32)).backward(dy.float() @ w.float())
+        ref = p32.grad
+        dx = torch.empty(M, N, dtype=dtype, device=DEV)
+        db0 = torch.randn(N, generator=gen)
+        db = db0.clone().to(DEV)
+        K.gemm_dact(dy.to(DEV), w.to(DEV), dx, pre.to(DEV), db, act)
+        _assert_close(dx, ref, dtype)
+        exp_db = db0.double() + dx.double().cpu().sum(0)           # the sums are taken over the stored values
+        assert torch.allclose(db.double().cpu(), exp_db, rtol=1e-4, atol=2e-3 * math.sqrt(M)), (db.double().cpu() - exp_db).abs().max()
+        dx2 = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm_dact(dy.to(DEV), w.to(DEV), dx2, pre.to(DEV), None, act)
+        assert torch.equal(dx2, dx)
+
+
+def test_fast_gelu_of_the_bf16_path_over_its_whole_range(K):
+    """bf16 kernels evaluate erf by a rational approximation (|err| <= 1.5e-7): forward and gradient against
+    torch's erf GELU on a dense grid including both tails."""
+    x = torch.linspace(-12.0, 12.0, 64 * 1024).view(64, 1024)
+    xb = x.bfloat16()
+    y = K.bias_act_fwd(xb.to(DEV), None, 1)
+    ref = F.gelu(xb.double())                                   # fp32 erf loses the negative tail: 1 + erf(x) rounds to 0 / 2^-24
+    assert torch.allclose(y.double().cpu(), ref, rtol=2 ** -7, atol=2e-6), (y.double().cpu() - ref).abs().max()
+    ones = torch.ones_like(xb)
+    dx, _ = K.bias_act_bwd(xb.to(DEV), None, ones.to(DEV), 1, want_dbias=False)
+    x64 = xb.double().requires_grad_(True)
+    F.gelu(x64).sum().backward()
+    assert torch.allclose(dx.double().cpu(), x64.grad, rtol=2 ** -7, atol=2e-6), (dx.double().cpu() - x64.grad).abs().max()

@@ -1,0 +1,31 @@
+"""Isolated timing of the row-wise kernels on the r-layer shapes (GB/s against the bytes they must move)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from shg_vqa_amd import kernels as K
+from tools.gemm_shapes import bench
+dev = "cuda"
+R = 12576
+for cols in (768, 3072):
+    x = torch.randn(R, cols, device=dev).bfloat16()
+    dy = torch.randn(R, cols, device=dev).bfloat16()
+    bias = torch.randn(cols, device=dev)
+    t = bench(lambda: K.bias_act_fwd(x, bias, 1))
+    print("bias_act_fwd  %5d  %7.1f us  %6.0f GB/s" % (cols, t, 2 * x.numel() * 2 / t / 1e3))
+    t = bench(lambda: K.bias_act_bwd(x, None, dy, 1, want_dbias=True))
+    print("bias_act_bwd  %5d  %7.1f us  %6.0f GB/s" % (cols, t, 3 * x.numel() * 2 / t / 1e3))
+    part = torch.randn(K.colsum_partials(R), cols, device=dev)
+    out = torch.zeros(cols, device=dev)
+    t = bench(lambda: K.colsum_finish(part, out, True))
+    print("colsum_finish %5d  %7.1f us  %6.0f GB/s (partials %d)" % (cols, t, part.numel() * 4 / t / 1e3, part.shape[0]))
+cols = 768
+x = torch.randn(R, cols, device=dev).bfloat16()
+res = torch.randn(R, cols, device=dev).bfloat16()
+g = torch.ones(cols, device=dev); b = torch.zeros(cols, device=dev); bias = torch.randn(cols, device=dev)
+seed = torch.tensor([1, 0], dtype=torch.int64, device=dev)
+for p in (0.0, 0.1):
+    y, z, mean, rstd = K.ln_fwd(x, bias, res, g, b, 1e-12, 0, p, seed, 3)
+    t = bench(lambda: K.ln_fwd(x, bias, res, g, b, 1e-12, 0, p, seed, 3))
+    print("ln_fwd p=%.1f          %7.1f us  %6.0f GB/s" % (p, t, 4 * x.numel() * 2 / t / 1e3))
+    t = bench(lambda: K.ln_bwd(x, z, None, bias, g, mean, rstd, 0, p, seed, 3))
+    print("ln_bwd p=%.1f          %7.1f us  %6.0f GB/s" % (p, t, 4 * x.numel() * 2 / t / 1e3))
