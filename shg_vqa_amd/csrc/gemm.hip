@@ -475,16 +475,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // source address = wave-uniform base of the K-step + a per-lane byte offset computed once (the address math
+    // of 8 loads per K-step otherwise costs as many VALU cycles as the step's MFMAs)
+    uint32_t offa[NCH], offb[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        offa[i] = sa.lane_off(tid, i, NTHR);
+        offb[i] = sb.lane_off(tid, i, NTHR);
+    }
     auto stage_async = [&](int buf, int64_t k0) {
         char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            int t, row, cha, chb;
-            chunk_coord<T, NTHR, SrcA::KMAJOR>(tid, i, t, row, cha);
-            chunk_coord<T, NTHR, SrcB::KMAJOR>(tid, i, t, row, chb);
             char* dst = base + (NTHR * i + 64 * wave_u) * 16;         // wave-uniform; the hardware adds lane * 16
-            __builtin_amdgcn_global_load_lds((glb_ptr)sa.gaddr(i, t, row, cha, k0), (lds_ptr)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr)sb.gaddr(i, t, row, chb, k0), (lds_ptr)(dst + B_OFF), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(i, k0) + offa[i]), (lds_ptr)dst, 16, 0, 0);
+            if constexpr (SrcB::DYN) {                                // per-K-step gather positions (conv weight gradient)
+                int t, row, chb;
+                chunk_coord<T, NTHR, SrcB::KMAJOR>(tid, i, t, row, chb);
+                __builtin_amdgcn_global_load_lds((glb_ptr)sb.gaddr(i, t, row, chb, k0), (lds_ptr)(dst + B_OFF), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((glb_ptr)(sb.k_base(i, k0) + offb[i]), (lds_ptr)(dst + B_OFF), 16, 0, 0);
+            }
         }
     };
     auto stage_ragged = [&](int buf, int64_t k0) {                     // predicated, zero-filled (K tail)
@@ -1003,6 +1014,11 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
     // (it only ever meets zero-filled data of the other operand).
     const int64_t ea = ((a_kmajor ? K : M) + epc - 1) / epc * epc, eb = ((b_kmajor ? K : N) + epc - 1) / epc * epc;
     if (lda < ea || ldb < eb || ldc < N) return fail_arg("gemm: leading dimension too small for 16-byte row reads");
+    {   // the kernels address an operand with 32-bit byte offsets from a per-K-step base
+        const int64_t es = dtype_ab == SHG_BF16 ? 2 : 4;
+        if ((a_kmajor ? M : (int64_t)64) * lda * es >= ((int64_t)1 << 32) || (b_kmajor ? N : (int64_t)64) * ldb * es >= ((int64_t)1 << 32))
+            return fail_arg("gemm: operand spans 4 GiB or more");
+    }
     hipStream_t st = (hipStream_t)stream;
     const int vlen = dtype_c == SHG_F32 ? 4 : 8;      // elements per 16-byte output vector
     const int vec_ok = (ldc % vlen == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) &&

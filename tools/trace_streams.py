@@ -26,6 +26,13 @@ print('concurrency histogram (ms):', {k: round(v / 1e6, 2) for k, v in sorted(co
 nb = int(last / 1e6) + 1
 sys.path.insert(0, __file__.rsplit('/', 1)[0])
 def fam(n):
+    if 'gemm8_kernel' in n:
+        cfg = '8'
+        if 'ConvColSrc' in n: return 'conv_wgrad_8'
+        if 'ConvWeightColSrc' in n: return 'conv_dgrad_8'
+        if 'ConvRowSrc' in n: return 'conv_fwd_8'
+        if 'PlainSrcIDF16bLb1EEES2_' in n: return 'gemm_NT_fwd_8'
+        return 'gemm_NN_dgrad_8'
     if 'gemm_kernel' in n:
         cfg = 'L' if 'Li4ELi4E' in n else 'S'
         if 'ConvColSrc' in n: return 'conv_wgrad_' + cfg
