@@ -173,8 +173,16 @@ class AGQAModel(nn.Module):
             feats, x, attn = self.bert_encoder((input_ids, input_masks, segment_ids))
             return M.mlp_head(self.logit_fc, x), attn
         feat = self.vid_encoder.encode(feat)
-        feats, x, attn = self.lxrt_encoder((input_ids, input_masks, segment_ids), (feat, pos))
-        logit = M.mlp_head(self.logit_fc, x)
+        E = engine()
+        # x-layers / pooler / answer head feed only `logit`; with the pre-cross-attention features going to the
+        # decoders (the default) nothing on the HGQA loss path waits for them
+        E.defer_x_layers = bool(a.task_hgqa and not a.after_cross_attn_feats)
+        try:
+            feats, x, attn = self.lxrt_encoder((input_ids, input_masks, segment_ids), (feat, pos))
+        finally:
+            E.defer_x_layers = False
+        with ops.deferred_branch():
+            logit = M.mlp_head(self.logit_fc, x)
         if a.task_vqa:
             return logit, attn
         if a.after_cross_attn_feats:
@@ -184,6 +192,7 @@ class AGQAModel(nn.Module):
             lang_feats, lang_mask, memory, _ = attn[-1]
         # rel_tgt_mask / act_tgt_mask arguments are ignored like in the reference (agqa_model.py:220, :241)
         rel_preds, act_preds, hg_in = self.hg_decoder(memory, rel_segment_ids, act_segment_ids)
+        ops.join_deferred_branch(lang_feats, logit)      # the language stream: question features + the deferred x-layers
         B = memory.shape[0]
         hgm = hg_mask.view(B, -1) if (a.use_hg_mask and hg_mask is not None) else None
         x, attn = self.hgq_encoder(lang_feats, lang_mask, hg_in, hgm)

@@ -59,6 +59,11 @@ class Engine:
         self.deferred_wgrads = []
         self.overlap_branches = os.environ.get("SHG_OVERLAP_BRANCHES", "1") != "0"   # independent sub-graphs (action decoder, language layers) on side streams
         self._aux_streams = {}
+        # --taskHGQA: the cross-modality x-layers, their pooler and the answer head only produce `logit`, which
+        # the HGQA loss never reads (agqaHGQA.py:344-345 uses hg_logit).  They stay on the language branch's
+        # stream, off the critical path, until AGQAModel.forward joins it (ops.Branch.reenter / join)
+        self.defer_x_layers = False
+        self.deferred_branch = None
         self.kernel_events = None        # bench.py: list collecting (start, end) events of the dominant kernel
         self.pending_clip = None
 
@@ -73,6 +78,7 @@ class Engine:
         """Resets the per-step call-site counter (the device-side step counter is advanced by the
         optimiser so that hipGraph replays see fresh masks)."""
         self._stream_id = 0
+        self.deferred_branch = None
 
     def next_stream_id(self):
         self._stream_id += 1

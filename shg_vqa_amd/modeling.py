@@ -494,9 +494,18 @@ class NoCapsEncoder(nn.Module):
         for layer in self.r_layers:
             visn_feats, _ = layer(visn_feats, visn_attention_mask)
         visn_out = visn_feats
-        branch.join(lang_feats)
-        for layer in self.x_layers:
-            lang_feats, visn_feats, _ = layer(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
+        E = engine()
+        if E.defer_x_layers and branch.side is not None and E.deferred_branch is None:
+            # --taskHGQA: nothing on the loss path reads the x-layers' output; they continue on the language
+            # stream (which first waits for the relation layers' output) and the main stream goes on to the decoders
+            with branch.extend(visn_feats):
+                for layer in self.x_layers:
+                    lang_feats, visn_feats, _ = layer(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
+            E.deferred_branch = branch
+        else:
+            branch.join(lang_feats)
+            for layer in self.x_layers:
+                lang_feats, visn_feats, _ = layer(lang_feats, lang_attention_mask, visn_feats, visn_attention_mask)
         return lang_feats, visn_feats, ([], [], [], [], [], (lang_out, lang_attention_mask, visn_out, visn_attention_mask))
 
 
@@ -549,7 +558,8 @@ class NoCapsModel(BertPreTrainedModel):
         ext_v = additive_mask(vmask, input_ids) if vmask is not None else None
         emb = self.embeddings(input_ids, token_type_ids)
         lang, visn, probs = self.encoder(emb, ext, visn_feats=visual_feats, visn_attention_mask=ext_v)
-        pooled = self.pooler(visn, lang)
+        with ops.deferred_branch():                  # (the x-layers' stream, when they were deferred)
+            pooled = self.pooler(visn, lang)
         return (lang, visn), pooled, probs
 
 

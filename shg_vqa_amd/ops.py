@@ -50,6 +50,28 @@ def _padded_rows(dy2):
     return buf[:, :n]
 
 
+class _NoBranch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def deferred_branch():
+    """Context that continues the engine's deferred branch (if any) - see Engine.defer_x_layers."""
+    b = engine().deferred_branch
+    return b.extend() if b is not None else _NoBranch()
+
+
+def join_deferred_branch(*outs):
+    E = engine()
+    if E.deferred_branch is not None:
+        E.deferred_branch.main = torch.cuda.current_stream()
+        E.deferred_branch.join(*outs)
+        E.deferred_branch = None
+
+
 class Branch:
     """Runs an independent sub-graph of the model on a side stream (with-block), e.g. the action decoder
     beside the relation decoder.  Autograd replays each backward node on the stream of its forward, so
@@ -75,6 +97,14 @@ class Branch:
         if self.side is not None:
             self.ctx.__exit__(*a)
         return False
+
+    def extend(self, *inputs):
+        """Re-enters the branch later for more work that also reads `inputs` from the main stream
+        (use as `with branch.extend(x):`)."""
+        if self.side is not None:
+            self.main = torch.cuda.current_stream()
+            self.inputs = inputs
+        return self
 
     def join(self, *outs):
         """Main stream waits for the branch; `outs` are branch results the main stream will read."""
