@@ -148,11 +148,19 @@ class AGQA:
             logit, rel_logit, act_logit, hg_logit, _ = self.model(
                 b["feat"], b["pos"], input_ids=b["input_ids"], input_masks=b["input_mask"], segment_ids=b["segment_ids"],
                 rel_segment_ids=rel_seg, act_segment_ids=act_seg, hg_mask=b.get("hg_mask"))
+            # the three losses are independent chains of small, latency-bound kernels (the Hungarian solver runs
+            # 180 us on a fraction of the chip): the two set losses go to side streams, the BCE stays here
+            side = os.environ.get("SHG_LOSS_BRANCH", "1") != "0"
+            br_r, br_a = ops.Branch(2 if side else -1, rel_logit), ops.Branch(1 if side else -1, act_logit)
+            with br_r:
+                rs, rgrid, rq, rt = ops.set_loss(rel_logit, b["rel_triplets"].view(-1, self.num_rel), b["lengths"].view(-1),
+                                                 self.empty_weight, self.num_rel)
+            with br_a:
+                as_, agrid, aq, at = ops.set_loss(act_logit, b["act_tokens"].view(-1, self.num_act),
+                                                  b["act_lengths"].view(-1), self.empty_weight_acts, self.num_act)
             bce = ops.bce_with_logits_times_c(hg_logit, b["target"])
-            rs, rgrid, rq, rt = ops.set_loss(rel_logit, b["rel_triplets"].view(-1, self.num_rel), b["lengths"].view(-1),
-                                             self.empty_weight, self.num_rel)
-            as_, agrid, aq, at = ops.set_loss(act_logit, b["act_tokens"].view(-1, self.num_act), b["act_lengths"].view(-1),
-                                              self.empty_weight_acts, self.num_act)
+            br_r.join(rs, rgrid, rq, rt)
+            br_a.join(as_, agrid, aq, at)
             if self.world is not None:
                 rs, as_ = self.world.global_loss_sums(rs), self.world.global_loss_sums(as_)
             rel_ce, act_ce = rs[0] / rs[1], as_[0] / as_[1]

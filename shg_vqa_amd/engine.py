@@ -159,7 +159,7 @@ class Engine:
 
     def aux_stream(self, i):
         """Side stream for an independent branch of the model (None: run it inline)."""
-        if not self.overlap_branches or self.device.type != "cuda":
+        if not self.overlap_branches or self.device.type != "cuda" or i < 0:
             return None
         if i not in self._aux_streams:
             self._aux_streams[i] = torch.cuda.Stream(device=self.device)

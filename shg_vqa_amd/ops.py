@@ -450,13 +450,15 @@ class _VisualConvTokens(torch.autograd.Function):
         # conv2: GELU', bias grad, weight grad, input grad
         d2, part = K.bias_act_bwd(pre2, None, d_tok, ACT_GELU, want_dbias=True)
         _acc_vec(part, b2)
+        # input gradient of conv2 = the forward gather over dy padded by (4 in T, 1 in H/W); the kernel reads
+        # the weight flipped / transposed in place.  It is issued BEFORE conv2's weight gradient: both fill the chip,
+        # and only the input gradient is on the critical path (-> d1 -> conv1's weight gradient, the last kernel
+        # of backward), so the side stream's conv2 wgrad waits for it instead of sharing the CUs with it.
+        d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
+        d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2))
         with _WgradStream(y1p, d2):
             K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
         E.grad_written(w2)
-        # input gradient of conv2 = the forward gather over dy padded by (4 in T, 1 in H/W); the kernel reads
-        # the weight flipped / transposed in place
-        d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
-        d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2))
         d1, part1 = K.bias_act_bwd(pre1, None, d_y1, ACT_GELU, want_dbias=True)
         _acc_vec(part1, b1)
         with _WgradStream(x_cl, d1):
