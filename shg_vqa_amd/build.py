@@ -14,6 +14,11 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libshgvqa.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+# per-file extras.  attention.hip: the softmax works on the MFMA results with VALU instructions every key tile
+# (scale, max, exp, rescale of the output accumulators); with the accumulators in AGPRs (the compiler's default
+# at this register count) each touch is a v_accvgpr_read/write: ~80 extra VALU instructions per tile in a
+# VALU-bound loop.  VGPR-form MFMAs remove them and raise the occupancy of the backward kernels.
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _sources():
@@ -31,7 +36,7 @@ def _compile(src):
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), _headers_mtime()):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", path, "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, res.stderr[-4000:]))

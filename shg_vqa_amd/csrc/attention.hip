@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
     load_tile64_async<T>(smem + TL::BYTES, vbase, P.v_ss, min(64, P.Sk), tid);
     const Frag<T> qf0 = glb_row_frag(qptr, 0, g), qf1 = glb_row_frag(qptr, 32, g);
     const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
-    const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)P.Sk;
+    const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)((P.Sk + 1) & ~1);   // even row pitch
 
     f32x4 acc_o[4];
 #pragma unroll
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
                 rs += p;
                 if (P.drop_thr) {
                     const int key = kb + 16 * kt + 4 * g + r;
-                    p = dropout_keep(seed, drop_row + (uint64_t)key, P.drop_thr) ? p * P.drop_scale : 0.f;
+                    p = dropout_keep_run(seed, (drop_row + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? p * P.drop_scale : 0.f;
                 }
                 s[kt][r] = p;
             }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
     }
     const float lse_q = lse[stat];
     const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
-    const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)P.Sk;
+    const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)((P.Sk + 1) & ~1);   // even row pitch
 
     f32x4 acc[4];
 #pragma unroll
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
                 if (MASK != SHG_MASK_NONE) val += mask_value<MASK>(P.mask, b, qrow, min(key, P.Sk - 1), P.Sk);
                 float p = (key < P.Sk) ? __expf(val - lse_q) : 0.f;
                 float dpe = dp[kt][r];
-                if (P.drop_thr) dpe = dropout_keep(seed, drop_row + (uint64_t)key, P.drop_thr) ? dpe * P.drop_scale : 0.f;
+                if (P.drop_thr) dpe = dropout_keep_run(seed, (drop_row + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? dpe * P.drop_scale : 0.f;
                 s[kt][r] = p * (dpe - dl);
             }
 #pragma unroll
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                 float dpe = dp[qt][r];
                 float pd = p;
                 if (P.drop_thr) {
-                    const bool keep = dropout_keep(seed, (drop_bh + (uint64_t)min(query, P.Sq - 1)) * (uint64_t)P.Sk + (uint64_t)krow, P.drop_thr);
+                    const bool keep = dropout_keep(seed, (drop_bh + (uint64_t)min(query, P.Sq - 1)) * (uint64_t)((P.Sk + 1) & ~1) + (uint64_t)krow, P.drop_thr);
                     dpe = keep ? dpe * P.drop_scale : 0.f;
                     pd = keep ? p * P.drop_scale : 0.f;
                 }

@@ -73,18 +73,35 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // ------------------------------------------------------------------ counter-based dropout RNG
-// keep(element) is a pure function of (seed, stream, element index) so that backward kernels
-// regenerate the forward mask.  Two rounds of a 64->32 bit mix (splitmix-style).
-__device__ __forceinline__ uint32_t mix_u32(uint64_t seed, uint64_t idx) {
-    uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 16);
+// keep(element) is a pure function of (seed, stream, element index) so that backward kernels regenerate
+// the forward mask.  One 32-bit hash serves the PAIR of elements (2p, 2p+1): 16 random bits each, compared
+// with the upper 16 bits of the threshold (p is resolved to 1/65536).  All arithmetic is 32-bit: the former
+// 64-bit splitmix cost ~15 integer multiplies per element, which made the dropout the most expensive part of
+// the attention and LayerNorm kernels.  (Integer hash: the "lowbias32" constants of Wellons' hash prospector.)
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
 }
-// threshold = (uint32_t)(p * 2^32); keep iff mix >= threshold
+// random word of element pair `pair` (= element index >> 1); `seed` comes from dropout_seed()
+__device__ __forceinline__ uint32_t dropout_pair_word(uint64_t seed, uint64_t pair) {
+    const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
+    return hash32(lo * 0x9E3779B1u + (uint32_t)seed + hi * 0x85EBCA77u) ^ (uint32_t)(seed >> 32);
+}
+__device__ __forceinline__ bool dropout_keep_word(uint32_t word, int odd, uint32_t threshold) {
+    return ((word >> (odd ? 16 : 0)) & 0xFFFFu) >= (threshold >> 16);
+}
+// threshold = (uint32_t)(p * 2^32); keep iff the element's 16 random bits >= threshold >> 16
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t threshold) {
-    return mix_u32(seed, idx) >= threshold;
+    return dropout_keep_word(dropout_pair_word(seed, idx >> 1), (int)(idx & 1), threshold);
+}
+// element j of a run that starts at the EVEN index 2 * pair_base (j a compile-time constant after unrolling:
+// the two elements of a pair then share one hash)
+__device__ __forceinline__ bool dropout_keep_run(uint64_t seed, uint64_t pair_base, int j, uint32_t threshold) {
+    return dropout_keep_word(dropout_pair_word(seed, pair_base + (uint64_t)(j >> 1)), j & 1, threshold);
 }
 __host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) {
     double t = (double)p * 4294967296.0;
@@ -98,7 +115,10 @@ __host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) {
 // separates the call sites inside one step.
 __device__ __forceinline__ uint64_t dropout_seed(const uint64_t* seed_state, uint64_t stream_id) {
     uint64_t s = seed_state ? (seed_state[0] + 0x632BE59BD9B4E019ull * (seed_state[1] + 1)) : 0x1234567ull;
-    return s ^ (stream_id * 0xD1342543DE82EF95ull);
+    s ^= stream_id * 0xD1342543DE82EF95ull;
+    // both halves diffused (once per thread): the per-element hash only adds the low word to the counter
+    const uint32_t lo = hash32((uint32_t)s ^ hash32((uint32_t)(s >> 32))), hi = hash32((uint32_t)(s >> 32) + 0x9E3779B9u ^ lo);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

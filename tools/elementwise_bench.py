@@ -29,3 +29,19 @@ for p in (0.0, 0.1):
     print("ln_fwd p=%.1f          %7.1f us  %6.0f GB/s" % (p, t, 4 * x.numel() * 2 / t / 1e3))
     t = bench(lambda: K.ln_bwd(x, z, None, bias, g, mean, rstd, 0, p, seed, 3))
     print("ln_bwd p=%.1f          %7.1f us  %6.0f GB/s" % (p, t, 4 * x.numel() * 2 / t / 1e3))
+
+# attention, r-layer shape (self, S=393) and decoder cross shape (Sq=128, Sk=393)
+for (Sq, Sk) in ((393, 393), (128, 393)):
+    B, H = 32, 12
+    q = torch.randn(B, Sq, H * 64, device=dev).bfloat16()
+    k = torch.randn(B, Sk, H * 64, device=dev).bfloat16()
+    v = torch.randn(B, Sk, H * 64, device=dev).bfloat16()
+    for p in (0.0, 0.1):
+        o, lse = K.attention_fwd(q, k, v, H, K.MASK_NONE, None, 0.125, p, seed, 5)
+        do = torch.randn_like(o)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        fl = 4.0 * B * H * Sq * Sk * 64
+        t = bench(lambda: K.attention_fwd(q, k, v, H, K.MASK_NONE, None, 0.125, p, seed, 5))
+        print("attn fwd  Sq=%d Sk=%d p=%.1f  %7.1f us  %5.0f TF" % (Sq, Sk, p, t, fl / t / 1e6))
+        t = bench(lambda: K.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, H, K.MASK_NONE, None, 0.125, p, seed, 5))
+        print("attn bwd  Sq=%d Sk=%d p=%.1f  %7.1f us  %5.0f TF" % (Sq, Sk, p, t, 2.5 * fl / t / 1e6))
