@@ -392,13 +392,22 @@ def conv1_forward(feat, w1, b1, bufs=None):
     This is the dominant kernel of the step; bench.py times it with events on this stream."""
     E = engine()
     cdt = E.compute_dtype
-    B, C, T, H, W = feat.shape
+    cin = w1.shape[1]
+    # features straight from the cache (feature_cache.py) are already channels-last: [B, T, H, W, C]
+    channels_last = feat.shape[-1] == cin and feat.shape[1] != cin
+    if channels_last:
+        B, T, H, W, C = feat.shape
+    else:
+        B, C, T, H, W = feat.shape
     if bufs is None:
         bufs = (torch.zeros((B, T, H + 2, W + 2, C), dtype=cdt, device=feat.device),
                 torch.zeros((B, T - 4, H + 2, W + 2, w1.shape[0]), dtype=cdt, device=feat.device),
                 torch.empty((B, T - 4, H, W, w1.shape[0]), dtype=cdt, device=feat.device))
     x_cl, y1p, pre1 = bufs
-    K.ncdhw_to_padded_cl(feat.float().contiguous(), cdt, out=x_cl)
+    if channels_last:
+        x_cl[:, :, 1:-1, 1:-1].copy_(feat)                 # the zero border stays as allocated
+    else:
+        K.ncdhw_to_padded_cl(feat.float().contiguous(), cdt, out=x_cl)
     K.conv_workspace(B, T, H, W, feat.device)
     evs = getattr(E, "kernel_events", None)
     if evs is not None:

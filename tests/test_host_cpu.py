@@ -114,3 +114,29 @@ def test_no_cpu_fallback():
         K.bias_act_fwd(torch.zeros(4, 8), None, 0)
     with pytest.raises(ValueError):
         K.hungarian_per_frame(torch.zeros(2, 8, 10), torch.zeros(2, 8, dtype=torch.int64), torch.zeros(2, dtype=torch.int32))
+
+
+def test_feature_cache_round_trip_and_prefetch_order(tmp_path):
+    """cached slow_r50-shaped features (bf16, channels-last) and the double-buffered loader."""
+    import torch
+    from shg_vqa_amd.feature_cache import FeatureCache, PrefetchLoader, write_feature_cache
+    g = torch.Generator().manual_seed(0)
+    feats = [torch.randn(64, 6, 3, 3, generator=g) for _ in range(9)]
+    prefix = str(tmp_path / "clips")
+    assert write_feature_cache(prefix, feats, ids=["vid%d" % i for i in range(9)]) == 9
+    cache = FeatureCache(prefix)
+    assert len(cache) == 9 and cache.shape == (6, 3, 3, 64) and cache.index["vid7"] == 7
+    for i in (0, 4, 8):
+        assert torch.equal(cache[i], feats[i].permute(1, 2, 3, 0).to(torch.bfloat16))
+    batches = [[0, 1, 2, 3], [8, 7], [4, 4, 5, 6], [2]]
+    got = [b.clone() for b in PrefetchLoader(cache, batches, device="cpu")]
+    assert [x.shape[0] for x in got] == [4, 2, 4, 1]
+    for b, x in zip(batches, got):
+        for j, i in enumerate(b):
+            assert torch.equal(x[j], cache[i])
+    # a truncated file is rejected
+    with open(prefix + ".feat", "ab") as f:
+        f.write(b"\0\0")
+    import pytest
+    with pytest.raises(ValueError):
+        FeatureCache(prefix)

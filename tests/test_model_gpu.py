@@ -293,3 +293,28 @@ def test_training_loop_entry_points_run_and_learn(tmp_path):
     agqa.load(os.path.join(str(tmp_path), "LAST"))
     assert agqa.predict(valid) == p1
     assert 0.0 <= agqa.evaluate(valid) <= 1.0
+
+
+def test_cached_channels_last_features_feed_conv1_like_the_ncdhw_tensor(tmp_path):
+    """feature_cache.py: bf16 channels-last clips through the pinned double-buffered loader give the first
+    convolution exactly the input the NCDHW fp32 path builds."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from shg_vqa_amd import ops
+    from shg_vqa_amd.engine import engine
+    from shg_vqa_amd.feature_cache import FeatureCache, PrefetchLoader, write_feature_cache
+    tr = _build(torch.bfloat16)
+    gen = torch.Generator().manual_seed(5)
+    clips = [torch.randn(2048, 16, 7, 7, generator=gen) for _ in range(5)]
+    prefix = str(tmp_path / "feats")
+    write_feature_cache(prefix, clips)
+    cache = FeatureCache(prefix)
+    w1, b1 = tr._conv1_params()
+    batches = [[0, 1], [2, 3], [4, 0]]
+    junk = torch.randn(4096, 4096, device=DEV)
+    for idx, dev_batch in zip(batches, PrefetchLoader(cache, batches, device=DEV)):
+        x_cl, y1p, pre1 = ops.conv1_forward(dev_batch, w1, b1)
+        ref = torch.stack([clips[i] for i in idx]).to(DEV)
+        x_ref, y_ref, pre_ref = ops.conv1_forward(ref, w1, b1)
+        junk = junk @ junk * 1e-4                     # keep the consumer stream busy while the next copy runs
+        assert torch.equal(x_cl, x_ref) and torch.equal(y1p, y_ref) and torch.equal(pre1, pre_ref)
