@@ -51,7 +51,9 @@ const char* shg_last_error_string(void);
  * out_prob[:, tgt_ids] gather, the .cpu() copy and the python loop over
  * scipy.optimize.linear_sum_assignment; also builds the target-class grid of
  * AGQA.loss_labels / get_target_classes (tasks/agqaHGQA.py:178-220).
- *   logits     [n_frames, per_frame, n_classes]  (dtype)      per_frame <= 8
+ *   logits     [n_frames, per_frame, n_classes]  (dtype)      per_frame <= 128.  per_frame <= 8 (the per-frame problems of
+ *              --LossHGPerFrame): one lane per problem; 9..128 (per-clip matching, matcher.py:82-104, one problem per
+ *              sample with per_frame = num_queries): one wave per problem, the column scan spread over the lanes
  *   tgt        [n_frames, per_frame] int64, class ids of the frame's targets, first tgt_len[f] valid
  *   tgt_len    [n_frames] int32 (0..per_frame)
  *   out_query  [n_frames, per_frame] int64: matched query index within the frame, ascending, -1 padded

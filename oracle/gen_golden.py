@@ -206,6 +206,36 @@ def gen_lsap():
     print("lsap done:", len(costs), "problems, scipy", scipy.__version__)
 
 
+def gen_matcher_clip():
+    """Per-clip branch of the REAL reference matcher (lxrt/matcher.py:82-104, loss_hg_per_frame=False): one
+    assignment problem per sample, num_queries x (number of labels in the clip)."""
+    from . import ref_harness
+    R = ref_harness.load()
+    torch = R.torch
+    m = R.matcher.HungarianMatcher(cost_class=1, loss_hg_per_frame=False)
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    for tag, (B, Q, C) in {"rel": (6, 128, 96), "act": (6, 48, 40), "ties": (4, 128, 24)}.items():
+        logits = torch.randn(B, Q, C, generator=g)
+        if tag == "ties":                                   # few distinct logit values: many exact ties in the cost
+            logits = torch.round(logits * 2) / 2
+        lens = [0, Q, 1] + [int(torch.randint(2, Q, (1,), generator=g)) for _ in range(B - 3)]
+        tgt = -torch.ones(B, Q, dtype=torch.int64)
+        targets = []
+        for b in range(B):
+            lab = torch.randint(1, C, (lens[b],), generator=g)      # duplicates are the norm
+            tgt[b, :lens[b]] = lab
+            targets.append({"labels": lab})
+        idx = m({"pred_logits": logits}, targets)
+        oq, ot = -torch.ones(B, Q, dtype=torch.int64), -torch.ones(B, Q, dtype=torch.int64)
+        for b, (i, j) in enumerate(idx):
+            oq[b, :len(i)], ot[b, :len(j)] = i, j
+        out.update({tag + "_logits": logits.numpy(), tag + "_tgt": tgt.numpy(), tag + "_len": np.array(lens, np.int32),
+                    tag + "_q": oq.numpy(), tag + "_t": ot.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "matcher_clip.npz"), **out)
+    print("matcher_clip done")
+
+
 def gen_bertadam():
     """Four BertAdam steps (the first has lr 0) on three small tensors, with clipping."""
     from . import ref_harness
@@ -239,7 +269,7 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("hgqa", "star", "q", "lsap", "bertadam"):
+        for v in ("hgqa", "star", "q", "lsap", "bertadam", "matcher_clip"):
             subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", v], env=env,
                                   cwd=os.path.dirname(HERE))
     elif what == "hgqa":
@@ -250,6 +280,8 @@ def main():
         gen_q()
     elif what == "lsap":
         gen_lsap()
+    elif what == "matcher_clip":
+        gen_matcher_clip()
     elif what == "bertadam":
         gen_bertadam()
     else:

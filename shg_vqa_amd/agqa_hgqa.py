@@ -16,7 +16,7 @@ import torch.nn as nn
 from . import ops
 from .agqa_model import AGQAModel
 from .engine import engine
-from .entry import frame_segment_ids
+from .entry import clip_targets_device, frame_segment_ids
 from .matcher import HungarianMatcher
 from .optimization import BertAdam, clip_grad_norm_
 
@@ -152,12 +152,17 @@ class AGQA:
             # 180 us on a fraction of the chip): the two set losses go to side streams, the BCE stays here
             side = os.environ.get("SHG_LOSS_BRANCH", "1") != "0"
             br_r, br_a = ops.Branch(2 if side else -1, rel_logit), ops.Branch(1 if side else -1, act_logit)
+            if a.loss_hg_per_frame:                  # one assignment problem per frame (matcher.py:62-80)
+                r_tgt, r_len, r_per = b["rel_triplets"].view(-1, self.num_rel), b["lengths"].view(-1), self.num_rel
+                a_tgt, a_len, a_per = b["act_tokens"].view(-1, self.num_act), b["act_lengths"].view(-1), self.num_act
+            else:                                    # one per clip over all its labels (matcher.py:82-104)
+                r_tgt, r_len = clip_targets_device(b["rel_triplets"].view(B, self.num_situations, self.num_rel), b["lengths"])
+                a_tgt, a_len = clip_targets_device(b["act_tokens"].view(B, self.num_situations, self.num_act), b["act_lengths"])
+                r_per, a_per = rel_logit.shape[1], act_logit.shape[1]
             with br_r:
-                rs, rgrid, rq, rt = ops.set_loss(rel_logit, b["rel_triplets"].view(-1, self.num_rel), b["lengths"].view(-1),
-                                                 self.empty_weight, self.num_rel)
+                rs, rgrid, rq, rt = ops.set_loss(rel_logit, r_tgt, r_len, self.empty_weight, r_per)
             with br_a:
-                as_, agrid, aq, at = ops.set_loss(act_logit, b["act_tokens"].view(-1, self.num_act),
-                                                  b["act_lengths"].view(-1), self.empty_weight_acts, self.num_act)
+                as_, agrid, aq, at = ops.set_loss(act_logit, a_tgt, a_len, self.empty_weight_acts, a_per)
             bce = ops.bce_with_logits_times_c(hg_logit, b["target"])
             br_r.join(rs, rgrid, rq, rt)
             br_a.join(as_, agrid, aq, at)

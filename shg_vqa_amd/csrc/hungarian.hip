@@ -167,6 +167,167 @@ __global__ __launch_bounds__(64) void lsap_batched_kernel(const float* __restric
     for (int k = 0; k < width; ++k) { out_r[(int64_t)p * width + k] = oq[k]; out_c[(int64_t)p * width + k] = ot[k]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Larger problems (the per-clip branch of the matcher, matcher.py:82-104: num_queries x labels-of-the-clip,
+// up to 128 x 128): one wave per problem.  Same algorithm and float64 arithmetic; the column scan of
+// every shortest-path step is spread over the 64 lanes (column it, it+64, ..) and the lane results are
+// combined so that the winner is the one SciPy's sequential scan picks: the minimum; on an exact tie the LAST
+// unassigned column in scan order, or - when no tied column is unassigned - the FIRST in scan order.
+// ------------------------------------------------------------------------------------------------
+constexpr int WMAX = 128;
+
+struct WaveLsap {                                   // carved from dynamic LDS
+    float* cost;                                    // [nr][ldc] solver orientation
+    double *u, *v, *spc;
+    int *col4row, *row4col, *path, *remaining, *q2t;
+    unsigned char *in_sr, *in_sc;
+};
+
+__device__ void wave_lsap_solve(const WaveLsap& s, int nr, int nc, int ldc, int lane) {
+    for (int i = lane; i < nr; i += 64) { s.u[i] = 0.0; s.col4row[i] = -1; }
+    for (int j = lane; j < nc; j += 64) { s.v[j] = 0.0; s.row4col[j] = -1; }
+    __syncthreads();
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int r = lane; r < nr; r += 64) s.in_sr[r] = 0;
+        for (int j = lane; j < nc; j += 64) { s.in_sc[j] = 0; s.spc[j] = INFINITY; s.path[j] = -1; s.remaining[j] = nc - 1 - j; }
+        __syncthreads();
+        double min_val = 0.0;
+        int i = cur, sink = -1, n_rem = nc;
+        while (sink == -1) {
+            if (lane == 0) s.in_sr[i] = 1;
+            const double ui = s.u[i];
+            const float* crow = s.cost + (size_t)i * ldc;
+            // lane-local sequential scan over its columns (increasing it), SciPy's update rule
+            double lowest = INFINITY;
+            int best = -1, best_free = 0;
+            for (int it = lane; it < n_rem; it += 64) {
+                const int j = s.remaining[it];
+                const double r = min_val + (double)crow[j] - ui - s.v[j];
+                double sj = s.spc[j];
+                if (r < sj) { s.path[j] = i; s.spc[j] = r; sj = r; }
+                const int fr = s.row4col[j] == -1;
+                if (sj < lowest || (sj == lowest && fr)) { lowest = sj; best = it; best_free = fr; }
+            }
+            // combine: min value; tie -> unassigned beats assigned; unassigned: larger it; assigned: smaller it
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(lowest, o, 64);
+                const int ob = __shfl_xor(best, o, 64), of = __shfl_xor(best_free, o, 64);
+                bool take = false;
+                if (ob >= 0) {
+                    if (best < 0 || ov < lowest) take = true;
+                    else if (ov == lowest) {
+                        if (of != best_free) take = of > best_free;
+                        else take = of ? (ob > best) : (ob < best);
+                    }
+                }
+                if (take) { lowest = ov; best = ob; best_free = of; }
+            }
+            if (best < 0) return;                    // cannot happen with finite costs
+            min_val = lowest;
+            const int j = s.remaining[best];
+            const int rj = s.row4col[j];
+            __syncthreads();                         // every lane has read remaining[] / row4col[] of this step
+            if (rj == -1) sink = j; else i = rj;
+            if (lane == 0) {
+                s.in_sc[j] = 1;
+                s.remaining[best] = s.remaining[n_rem - 1];
+            }
+            --n_rem;
+            __syncthreads();
+        }
+        if (lane == 0) s.u[cur] += min_val;
+        for (int r = lane; r < nr; r += 64)
+            if (s.in_sr[r] && r != cur) s.u[r] += min_val - s.spc[s.col4row[r]];
+        for (int j = lane; j < nc; j += 64)
+            if (s.in_sc[j]) s.v[j] -= min_val - s.spc[j];
+        __syncthreads();
+        if (lane == 0) {
+            int j = sink;
+            for (;;) {
+                const int r = s.path[j];
+                s.row4col[j] = r;
+                const int prev = s.col4row[r];
+                s.col4row[r] = j;
+                j = prev;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void hungarian_wave_kernel(
+    const T* __restrict__ logits, int n_prob, int R, int C, const int64_t* __restrict__ tgt,
+    const int32_t* __restrict__ tgt_len, int64_t background, int64_t* __restrict__ out_q,
+    int64_t* __restrict__ out_t, int64_t* __restrict__ out_grid) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int lane = threadIdx.x, f = blockIdx.x;
+    if (f >= n_prob) return;
+    WaveLsap s;
+    char* p = wsm;
+    s.cost = (float*)p; p += (size_t)R * R * 4;
+    s.u = (double*)p; p += (size_t)R * 8;
+    s.v = (double*)p; p += (size_t)R * 8;
+    s.spc = (double*)p; p += (size_t)R * 8;
+    s.col4row = (int*)p; p += (size_t)R * 4;
+    s.row4col = (int*)p; p += (size_t)R * 4;
+    s.path = (int*)p; p += (size_t)R * 4;
+    s.remaining = (int*)p; p += (size_t)R * 4;
+    s.q2t = (int*)p; p += (size_t)R * 4;
+    s.in_sr = (unsigned char*)p; p += R;
+    s.in_sc = (unsigned char*)p;
+    const int n = min(max(tgt_len[f], 0), R);
+    const bool transposed = n < R;                  // SciPy transposes when rows (queries) > cols (targets)
+    int64_t* oq = out_q + (int64_t)f * R;
+    int64_t* ot = out_t + (int64_t)f * R;
+    for (int k = lane; k < R; k += 64) { oq[k] = -1; ot[k] = -1; if (out_grid) out_grid[(int64_t)f * R + k] = background; }
+    if (n == 0) return;
+    // cost = -softmax[q, tgt_t] (fp32), solver orientation [target][query] when transposed, else [query][target]
+    for (int q = 0; q < R; ++q) {
+        const T* row = logits + ((int64_t)f * R + q) * C;
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int c = lane; c < C; c += 64) sum += expf(to_f32(row[c]) - mx);
+        sum = wave_sum(sum);
+        for (int t = lane; t < n; t += 64) {
+            const int64_t cls = tgt[(int64_t)f * R + t];
+            const float pr = expf(to_f32(row[cls]) - mx) / sum;
+            if (transposed) s.cost[(size_t)t * R + q] = -pr; else s.cost[(size_t)q * R + t] = -pr;
+        }
+    }
+    __syncthreads();
+    wave_lsap_solve(s, transposed ? n : R, R, R, lane);     // (n == R: square, rows = queries)
+    // output: pairs ordered by query index
+    if (!transposed) {
+        for (int q = lane; q < R; q += 64) {
+            oq[q] = q;
+            ot[q] = s.col4row[q];
+            if (out_grid) out_grid[(int64_t)f * R + q] = tgt[(int64_t)f * R + s.col4row[q]];
+        }
+        return;
+    }
+    for (int q = lane; q < R; q += 64) s.q2t[q] = -1;
+    __syncthreads();
+    for (int t = lane; t < n; t += 64) s.q2t[s.col4row[t]] = t;
+    __syncthreads();
+    if (lane == 0) {
+        int k = 0;
+        for (int q = 0; q < R; ++q) {
+            const int t = s.q2t[q];
+            if (t >= 0) {
+                oq[k] = q;
+                ot[k] = t;
+                ++k;
+                if (out_grid) out_grid[(int64_t)f * R + q] = tgt[(int64_t)f * R + t];
+            }
+        }
+    }
+}
+
 }  // namespace shg
 
 extern "C" int shg_hungarian_per_frame(const void* logits, int dtype, int n_frames, int per_frame, int n_classes,
@@ -174,11 +335,29 @@ extern "C" int shg_hungarian_per_frame(const void* logits, int dtype, int n_fram
                                        int64_t* out_query, int64_t* out_target, int64_t* out_grid, void* stream) {
     using namespace shg;
     if (!logits || !tgt || !tgt_len || !out_query || !out_target) return fail_arg("hungarian: null pointer");
-    if (per_frame < 1 || per_frame > HMAX) return fail_arg("hungarian: per_frame must be in [1,8]");
+    if (per_frame < 1 || per_frame > WMAX) return fail_arg("hungarian: per_frame must be in [1,128]");
     if (n_frames < 0 || n_classes < 1) return fail_arg("hungarian: bad sizes");
     if (n_frames == 0) return 0;
-    dim3 grid((n_frames + FRAMES_PER_WAVE - 1) / FRAMES_PER_WAVE), block(64);
     hipStream_t st = (hipStream_t)stream;
+    if (per_frame > HMAX) {                          // one wave per problem (per-clip matching)
+        const size_t lds = (size_t)per_frame * per_frame * 4 + 3 * (size_t)per_frame * 8 + 5 * (size_t)per_frame * 4 +
+                           2 * (size_t)per_frame + 64;
+        if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("hungarian: bad dtype");
+        static bool raised = false;
+        if (!raised) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(hungarian_wave_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(hungarian_wave_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            raised = true;
+        }
+        if (dtype == SHG_F32)
+            hipLaunchKernelGGL(hungarian_wave_kernel<float>, dim3(n_frames), dim3(64), lds, st, (const float*)logits, n_frames,
+                               per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);
+        else
+            hipLaunchKernelGGL(hungarian_wave_kernel<bf16_t>, dim3(n_frames), dim3(64), lds, st, (const bf16_t*)logits, n_frames,
+                               per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);
+        return check_launch("hungarian_per_clip");
+    }
+    dim3 grid((n_frames + FRAMES_PER_WAVE - 1) / FRAMES_PER_WAVE), block(64);
     if (dtype == SHG_F32)
         hipLaunchKernelGGL(hungarian_per_frame_kernel<float>, grid, block, 0, st, (const float*)logits, n_frames,
                            per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);

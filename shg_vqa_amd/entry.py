@@ -87,6 +87,19 @@ def frame_segment_ids(batch, num_situations, per_frame, device):
     return torch.arange(num_situations, device=device).repeat_interleave(per_frame).unsqueeze(0).expand(batch, -1).contiguous()
 
 
+def clip_targets_device(triplets, lengths):
+    """Per-clip matching targets (convert_relations_to_features with loss_hg_per_frame=False, entry.py:87-89) built on
+    the device: the valid class ids of all frames, in frame order, left-packed.
+    triplets [B, T, per] int64, lengths [B, T] -> (tgt [B, T*per] int64, tgt_len [B] int32)."""
+    B, T, per = triplets.shape
+    valid = (torch.arange(per, device=triplets.device).view(1, 1, per) < lengths.view(B, T, 1)).view(B, -1)
+    flat = triplets.reshape(B, -1)
+    pos = valid.cumsum(1) - 1
+    out = torch.zeros((B, T * per + 1), dtype=torch.int64, device=triplets.device)
+    out.scatter_(1, torch.where(valid, pos, torch.full_like(pos, T * per)), flat)     # invalid slots land in the spare column
+    return out[:, :T * per].contiguous(), valid.sum(1).to(torch.int32)
+
+
 _MASK_CACHE = {}
 
 

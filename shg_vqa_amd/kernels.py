@@ -51,7 +51,7 @@ def hungarian_per_frame(logits, tgt, tgt_len, background=0, want_grid=True):
     _dev(logits, tgt, tgt_len)
     _need(logits.dim() == 3 and logits.is_contiguous(), "logits must be contiguous [N, R, C]")
     n, r, c = logits.shape
-    _need(1 <= r <= 8, "per_frame must be in [1, 8]")
+    _need(1 <= r <= 128, "queries per problem must be in [1, 128]")
     _need(tgt.shape == (n, r) and tgt.dtype == torch.int64 and tgt.is_contiguous(), "tgt must be int64 [N, R]")
     _need(tgt_len.shape == (n,) and tgt_len.dtype == torch.int32 and tgt_len.is_contiguous(), "tgt_len must be int32 [N]")
     oq = torch.empty((n, r), dtype=torch.int64, device=logits.device)

@@ -22,6 +22,20 @@ def pad_frame_targets(targets, per_frame, device):
     return tgt.to(device), lens.to(device)
 
 
+def pad_clip_targets(targets, num_queries, device):
+    """list (B) of {"labels": 1-D tensor of the clip's class ids} -> (tgt [B, num_queries] int64, len int32)."""
+    tgt = torch.zeros((len(targets), num_queries), dtype=torch.int64)
+    lens = torch.zeros(len(targets), dtype=torch.int32)
+    for i, d in enumerate(targets):
+        t = d["labels"].detach().to("cpu", torch.int64).reshape(-1)
+        n = int(t.numel())
+        if n > num_queries:
+            raise ValueError("a clip has %d targets but only %d queries" % (n, num_queries))
+        tgt[i, :n] = t
+        lens[i] = n
+    return tgt.to(device), lens.to(device)
+
+
 class HungarianMatcher(nn.Module):
     def __init__(self, cost_class: float = 1, loss_hg_per_frame: bool = False, clip_len: int = 16):
         super().__init__()
@@ -35,20 +49,26 @@ class HungarianMatcher(nn.Module):
         """Device-resident fast path: pred_logits [B,Q,C]; tgt [B*clip_len, Q/clip_len] int64 (class ids,
         first tgt_len valid); tgt_len int32.  -> (query_idx, target_idx, grid) int64 [B*clip_len, per]."""
         b, q, c = pred_logits.shape
-        per = q // self.clip_len
         # a positive cost_class scales all costs alike and cannot change the assignment
         if self.cost_class < 0:
             raise NotImplementedError("negative cost_class")
+        if not self.loss_hg_per_frame:
+            # per-clip branch (matcher.py:82-104): ONE problem per sample, num_queries x labels-of-the-clip;
+            # tgt [B, Q] / tgt_len [B]; solved by the wave-cooperative kernel (up to 128 queries)
+            return K.hungarian_per_frame(pred_logits.contiguous(), tgt, tgt_len)
+        per = q // self.clip_len
         return K.hungarian_per_frame(pred_logits.contiguous().view(b * self.clip_len, per, c), tgt, tgt_len)
 
     @torch.no_grad()
     def forward(self, outputs, targets):
-        """Reference signature: returns a list of (index_i, index_j) int64 CPU tensors, one per frame."""
-        if not self.loss_hg_per_frame:
-            raise NotImplementedError("only the --LossHGPerFrame branch (matcher.py:66-80) is on the hot path")
+        """Reference signature: returns a list of (index_i, index_j) int64 CPU tensors, one per frame
+        (--LossHGPerFrame) or one per sample (per-clip matching)."""
         logits = outputs["pred_logits"]
-        per = logits.shape[1] // self.clip_len
-        tgt, lens = pad_frame_targets(targets, per, logits.device)
+        if not self.loss_hg_per_frame:
+            tgt, lens = pad_clip_targets(targets, logits.shape[1], logits.device)
+        else:
+            per = logits.shape[1] // self.clip_len
+            tgt, lens = pad_frame_targets(targets, per, logits.device)
         oq, ot, _ = self.match_padded(logits, tgt, lens)
         oq, ot, lens = oq.cpu(), ot.cpu(), lens.cpu()
         return [(oq[i, : int(lens[i])].clone(), ot[i, : int(lens[i])].clone()) for i in range(oq.shape[0])]

@@ -140,3 +140,19 @@ def test_feature_cache_round_trip_and_prefetch_order(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         FeatureCache(prefix)
+
+
+def test_clip_targets_packing_matches_reference_converter():
+    """Per-clip targets: the reference flattens the unpadded per-frame targets (entry.py:87-89)."""
+    import torch
+    from shg_vqa_amd.entry import clip_targets_device, convert_relations_to_features
+    g = torch.Generator().manual_seed(3)
+    B, T, per = 5, 16, 8
+    lens = torch.randint(0, per + 1, (B, T), generator=g)
+    trip = torch.randint(1, 456, (B, T, per), generator=g) * (torch.arange(per).view(1, 1, per) < lens.view(B, T, 1))
+    tgt, n = clip_targets_device(trip, lens)
+    feats = convert_relations_to_features(trip, per, T, lens, loss_hg_per_frame=False)
+    for i, f in enumerate(feats):
+        assert int(n[i]) == len(f.targets)
+        assert tgt[i, :len(f.targets)].tolist() == list(f.targets)
+        assert (tgt[i, len(f.targets):] == 0).all()

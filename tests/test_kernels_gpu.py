@@ -636,3 +636,43 @@ def test_fast_gelu_of_the_bf16_path_over_its_whole_range(K):
     x64 = xb.double().requires_grad_(True)
     F.gelu(x64).sum().backward()
     assert torch.allclose(dx.double().cpu(), x64.grad, rtol=2 ** -7, atol=2e-6), (dx.double().cpu() - x64.grad).abs().max()
+
+
+# ------------------------------------------------------------------------------------------ per-clip matcher
+@pytest.mark.parametrize("tag", ["rel", "act", "ties"])
+def test_hungarian_per_clip_bit_exact_vs_reference_matcher_golden(K, golden_dir, tag):
+    """matcher.py:82-104 (loss_hg_per_frame=False): one 128 x n / 48 x n problem per sample; golden indices come from
+    the REAL reference matcher (oracle/gen_golden.py matcher_clip), including n = 0, n = Q, duplicate labels and
+    logits with few distinct values (exact ties in the cost matrix)."""
+    g = np.load(os.path.join(golden_dir, "matcher_clip.npz"))
+    logits = torch.from_numpy(g[tag + "_logits"]).to(DEV)
+    tgt = torch.from_numpy(g[tag + "_tgt"]).clamp(min=0).to(DEV)
+    lens = torch.from_numpy(g[tag + "_len"]).to(DEV)
+    oq, ot, grid = K.hungarian_per_frame(logits, tgt, lens)
+    assert np.array_equal(oq.cpu().numpy(), g[tag + "_q"]), tag
+    assert np.array_equal(ot.cpu().numpy(), g[tag + "_t"]), tag
+    # target grid: background except matched query <- its label
+    exp = torch.zeros_like(grid.cpu())
+    for b in range(oq.shape[0]):
+        n = int(g[tag + "_len"][b])
+        exp[b, torch.from_numpy(g[tag + "_q"][b, :n])] = torch.from_numpy(g[tag + "_tgt"][b])[torch.from_numpy(g[tag + "_t"][b, :n])]
+    assert torch.equal(grid.cpu(), exp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hungarian_per_clip_matches_oracle_on_model_sized_problems(K, dtype):
+    from oracle import shg_ref
+    gen = torch.Generator().manual_seed(12)
+    for (B, Q, C) in [(8, 128, 457), (8, 48, 158), (3, 24, 30)]:
+        logits = (torch.randn(B, Q, C, generator=gen) * 2).to(dtype)
+        lens = torch.randint(0, Q + 1, (B,), generator=gen)
+        labels = [torch.randint(1, C, (int(n),), generator=gen) for n in lens]
+        ref = shg_ref.hungarian_per_frame(logits.float(), labels, clip_len=1)
+        tgt = torch.zeros(B, Q, dtype=torch.int64)
+        for b, l in enumerate(labels):
+            tgt[b, :len(l)] = l
+        oq, ot, _ = K.hungarian_per_frame(logits.to(DEV), tgt.to(DEV), lens.to(torch.int32).to(DEV))
+        for b, (qi, ti) in enumerate(ref):
+            n = int(lens[b])
+            assert torch.equal(oq[b, :n].cpu(), qi) and torch.equal(ot[b, :n].cpu(), ti), (dtype, B, Q, b)
+            assert (oq[b, n:] == -1).all()

@@ -318,3 +318,41 @@ def test_cached_channels_last_features_feed_conv1_like_the_ncdhw_tensor(tmp_path
         x_ref, y_ref, pre_ref = ops.conv1_forward(ref, w1, b1)
         junk = junk @ junk * 1e-4                     # keep the consumer stream busy while the next copy runs
         assert torch.equal(x_cl, x_ref) and torch.equal(y1p, y_ref) and torch.equal(pre1, pre_ref)
+
+
+def test_per_clip_matching_losses_vs_oracle(golden_dir):
+    """Without --LossHGPerFrame the matcher solves one problem per clip (matcher.py:82-104) and the weighted CE runs
+    over (B, Q) slots (agqaHGQA.py:203-229): matcher interface, device-side target packing and both set losses."""
+    from oracle import shg_ref
+    from shg_vqa_amd.engine import engine
+    from shg_vqa_amd.matcher import HungarianMatcher
+    g = np.load(os.path.join(golden_dir, "agqa_hgqa_b2.npz"))
+    tr = _build(torch.float32)
+    tr.args.loss_hg_per_frame = False
+    tr.matcher = HungarianMatcher(cost_class=1, loss_hg_per_frame=False, clip_len=tr.clip_len)
+    cfg, batch = _oracle_batch("hgqa", g)
+    b = _device_batch(batch)
+    tr.model.eval()
+    engine().begin_step()
+    engine().zero_grad()
+    out = tr.forward_losses(b)
+    for key, logit, trip, lens, w in (("rel", out["rel_logit"], batch["rel_triplets"], batch["lengths"], tr.empty_weight),
+                                      ("act", out["act_logit"], batch["act_tokens"], batch["act_lengths"], tr.empty_weight_acts)):
+        B, T, per = trip.shape
+        labels = [torch.cat([trip[i, j, :int(lens[i, j])] for j in range(T)]) for i in range(B)]
+        lg = logit.detach().float().cpu()
+        idx = shg_ref.hungarian_per_frame(lg, labels, clip_len=1)
+        loss, err, grid = shg_ref.set_loss(lg, labels, idx, w.detach().float().cpu(), clip_len=1)
+        q, t = out[key + "_idx"]
+        for i, (qi, ti) in enumerate(idx):
+            n = len(qi)
+            assert torch.equal(q[i, :n].cpu(), qi) and torch.equal(t[i, :n].cpu(), ti), (key, i)
+        assert torch.equal(out[key + "_grid"].cpu(), grid)
+        assert abs(float(out[key + "_ce"]) - float(loss)) <= 1e-3 * max(abs(float(loss)), 1.0), (key, float(out[key + "_ce"]), float(loss))
+        # reference-style interface: list of (index_i, index_j) per sample
+        pairs = tr.matcher({"pred_logits": logit.detach()}, [{"labels": l} for l in labels])
+        for (qi, ti), (rq, rt) in zip(pairs, idx):
+            assert torch.equal(qi, rq) and torch.equal(ti, rt)
+    out["total"].backward()
+    engine().join_side_streams()
+    assert torch.isfinite(engine().grad_arena).all() and engine().grad_arena.abs().max() > 0

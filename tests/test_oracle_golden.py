@@ -118,3 +118,22 @@ def test_bertadam_and_clip_match_reference(golden_dir):
         shg_ref.bertadam_step(params, grads, state, lr=1e-3, step=s, t_total=20)
         for i in range(3):
             _close(params[str(i)], g[f"after{s}_{i}"], 1e-6, 1e-7)
+
+
+def test_oracle_per_clip_matching_equals_reference_matcher(golden_dir):
+    """matcher.py:82-104 through the REAL reference (golden) vs the oracle's per-clip call (clip_len = 1)."""
+    import numpy as np
+    import torch
+    from oracle import shg_ref
+    g = np.load(os.path.join(golden_dir, "matcher_clip.npz"))
+    for tag in ("rel", "act", "ties"):
+        logits = torch.from_numpy(g[tag + "_logits"])
+        lens = g[tag + "_len"]
+        labels = [torch.from_numpy(g[tag + "_tgt"][b, :int(lens[b])]) for b in range(logits.shape[0])]
+        for solver in (shg_ref.lsap_c, shg_ref.lsap_py):
+            if solver is shg_ref.lsap_py and tag != "act":
+                continue                                  # the pure-Python solver only on the small problems
+            idx = shg_ref.hungarian_per_frame(logits, labels, clip_len=1, solver=solver)
+            for b, (qi, ti) in enumerate(idx):
+                n = int(lens[b])
+                assert np.array_equal(qi.numpy(), g[tag + "_q"][b, :n]) and np.array_equal(ti.numpy(), g[tag + "_t"][b, :n]), (tag, b)
