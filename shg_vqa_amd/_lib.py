@@ -63,6 +63,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ShgError("libshgvqa.so is missing: run `python -m shg_vqa_amd.build` (or __graft_entry__.build())")
+        # ONE HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  When it is
+        # already loaded the dynamic loader binds our NEEDED entry to it; loaded the other way round the process would
+        # end up with two runtimes (torch's allocations are then unknown to the one our kernels launch through:
+        # "no ROCm-capable device").  So torch - and its runtime - always come first.
+        import torch
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
         handle = ctypes.CDLL(LIB_PATH)
         for name, (args, ret) in _SIGNATURES.items():
             fn = getattr(handle, name)
