@@ -3,6 +3,8 @@
 // writes (p, m, v, shadow) of 16 bytes per lane.
 #include <math.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace shg {
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
                                                        bf16_t* __restrict__ shadow, int64_t n,
                                                        const float* __restrict__ grad_norm, float max_norm, float lr,
                                                        float warmup, int64_t t_total, float b1, float b2, float eps,
-                                                       float wd, const int64_t* __restrict__ step_state) {
+                                                       float wd, const int64_t* __restrict__ step_state, int mode) {
     float clip = 1.f;
     if (grad_norm && max_norm > 0.f) clip = fminf(max_norm / (grad_norm[0] + 1e-6f), 1.f);
     double lr_d = (double)lr;
@@ -56,10 +58,9 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
     const float lr_t = (float)lr_d;
     const float one_b1 = 1.f - b1, one_b2 = 1.f - b2;
     const int64_t n4 = n / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
-        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
-        bf16x4 sv;
+    // pure streaming (30 bytes per parameter, every byte touched once): non-temporal accesses keep the arenas out of
+    // the L2 / Infinity Cache, and two independent vectors per iteration double the loads in flight per lane
+    auto update = [&](f32x4& pv, const f32x4& gv, f32x4& mv, f32x4& vv, bf16x4& sv) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float gg = gv[j] * clip;
@@ -69,10 +70,33 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
             pv[j] -= lr_t * upd;
             sv[j] = (bf16_t)pv[j];
         }
-        reinterpret_cast<f32x4*>(p)[i] = pv;
-        reinterpret_cast<f32x4*>(m)[i] = mv;
-        reinterpret_cast<f32x4*>(v)[i] = vv;
-        if (shadow) reinterpret_cast<bf16x4*>(shadow)[i] = sv;
+    };
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    f32x4* m4 = reinterpret_cast<f32x4*>(m);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    bf16x4* s4 = reinterpret_cast<bf16x4*>(shadow);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; mode && i + stride < n4; i += 2 * stride) {
+        const int64_t k = i + stride;
+        f32x4 pa = __builtin_nontemporal_load(p4 + i), ga = __builtin_nontemporal_load(g4 + i);
+        f32x4 ma = __builtin_nontemporal_load(m4 + i), va = __builtin_nontemporal_load(v4 + i);
+        f32x4 pb = __builtin_nontemporal_load(p4 + k), gb = __builtin_nontemporal_load(g4 + k);
+        f32x4 mb = __builtin_nontemporal_load(m4 + k), vb = __builtin_nontemporal_load(v4 + k);
+        bf16x4 sa, sb;
+        update(pa, ga, ma, va, sa);
+        update(pb, gb, mb, vb, sb);
+        __builtin_nontemporal_store(pa, p4 + i); __builtin_nontemporal_store(ma, m4 + i); __builtin_nontemporal_store(va, v4 + i);
+        __builtin_nontemporal_store(pb, p4 + k); __builtin_nontemporal_store(mb, m4 + k); __builtin_nontemporal_store(vb, v4 + k);
+        if (shadow) { s4[i] = sa; s4[k] = sb; }           // the bf16 operands are read again by the next step's GEMMs
+    }
+    for (; i < n4; i += stride) {
+        f32x4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+        bf16x4 sa;
+        update(pa, ga, ma, va, sa);
+        p4[i] = pa; m4[i] = ma; v4[i] = va;
+        if (shadow) s4[i] = sa;
     }
     if (blockIdx.x == 0)
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
@@ -125,9 +149,11 @@ extern "C" int shg_bertadam_arena(float* param, const float* grad, float* m, flo
     if (shadow_bf16 && (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)) return fail_arg("bertadam: shadow must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (n > 0) {
-        const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, 4096);
+        static const int adam_mode = []() { const char* e = getenv("SHG_BERTADAM_MODE"); return e ? atoi(e) : 1; }();
+        static const int64_t adam_blocks = []() { const char* e = getenv("SHG_BERTADAM_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)16384; }();   // measured: 2 048 .. 8 192 blocks 4.3-4.5 TB/s, 16 384 4.8
+        const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, adam_blocks);
         hipLaunchKernelGGL(bertadam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, m, v, (bf16_t*)shadow_bf16,
-                           n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state);
+                           n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state, adam_mode);
     }
     if (bump_step) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, st, step_state, (int64_t)1);
     return check_launch("bertadam_arena");

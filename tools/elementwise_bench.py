@@ -45,3 +45,11 @@ for (Sq, Sk) in ((393, 393), (128, 393)):
         print("attn fwd  Sq=%d Sk=%d p=%.1f  %7.1f us  %5.0f TF" % (Sq, Sk, p, t, fl / t / 1e6))
         t = bench(lambda: K.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, H, K.MASK_NONE, None, 0.125, p, seed, 5))
         print("attn bwd  Sq=%d Sk=%d p=%.1f  %7.1f us  %5.0f TF" % (Sq, Sk, p, t, 2.5 * fl / t / 1e6))
+
+# BertAdam over the model's 289 M gradient-receiving parameters
+n = 289038112
+pa = torch.randn(n, device=dev); ga = torch.randn(n, device=dev) * 1e-3; ma = torch.zeros(n, device=dev); va = torch.zeros(n, device=dev)
+sh = torch.empty(n, device=dev, dtype=torch.bfloat16)
+gn = torch.tensor([10.0], device=dev); st = torch.zeros(1, dtype=torch.int64, device=dev)
+t = bench(lambda: K.bertadam_arena(pa, ga, ma, va, sh, gn, 5.0, 1e-5, 0.1, 10000, step_state=st, bump_step=False), iters=5)
+print("bertadam 289M            %7.1f us  %6.0f GB/s" % (t, n * 30 / t / 1e3))
