@@ -167,7 +167,7 @@ class AGQA:
             br_r.join(rs, rgrid, rq, rt)
             br_a.join(as_, agrid, aq, at)
             if self.world is not None:
-                rs, as_ = self.world.global_loss_sums(rs), self.world.global_loss_sums(as_)
+                rs, as_ = self.world.global_loss_sums2(rs, as_)
             rel_ce, act_ce = rs[0] / rs[1], as_[0] / as_[1]
             # data parallel: CE terms are already global (their gradient sums to the global gradient);
             # the BCE mean is local, so it enters with 1/world (ddp.py)

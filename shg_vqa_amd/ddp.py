@@ -108,5 +108,12 @@ class GradReducer:
             return sums
         return _AllReduceSums.apply(sums)
 
+    def global_loss_sums2(self, a, b):
+        """Both set losses' sums in ONE collective (it sits on the critical path between forward and backward)."""
+        if self.world == 1:
+            return a, b
+        both = _AllReduceSums.apply(torch.cat([a, b]))
+        return both[:a.numel()], both[a.numel():]
+
     def bce_scale(self):
         return 1.0 / self.world

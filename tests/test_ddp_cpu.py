@@ -52,6 +52,13 @@ def _worker(rank, world, port, out):
         assert abs(loss.item() - 5.0 / 10.0) < 1e-6
         assert abs(sums.grad[0].item() - 1.0 / 10.0) < 1e-7
         assert red.bce_scale() == 0.5
+        # both set losses in one collective
+        a = torch.tensor([1.0 + rank, 2.0, 0.0, 1.0], requires_grad=True)
+        b = torch.tensor([3.0, 5.0 + rank, 1.0, 1.0], requires_grad=True)
+        ga, gb = red.global_loss_sums2(a * 1.0, b * 1.0)
+        (ga[0] / ga[1] + gb[0] / gb[1]).backward()
+        assert torch.allclose(ga.detach(), torch.tensor([3.0, 4.0, 0.0, 2.0])) and torch.allclose(gb.detach(), torch.tensor([6.0, 11.0, 2.0, 2.0]))
+        assert abs(a.grad[0].item() - 0.25) < 1e-7 and abs(b.grad[0].item() - 1.0 / 11.0) < 1e-7
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, "FAIL %r" % (e,)))
