@@ -8,6 +8,8 @@ and lets the data-parallel reducer know exactly when a gradient slice is final.
 
 mc = AGQA/src/lxrt/modeling_capsbert.py of the reference.
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -465,14 +467,24 @@ class _VisualConvTokens(torch.autograd.Function):
         # of backward), so the side stream's conv2 wgrad waits for it instead of sharing the CUs with it.
         d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
         d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2))
-        with _WgradStream(y1p, d2):
-            K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
-        E.grad_written(w2)
+        # The conv weight gradients are the last kernels of backward and fill the chip.  They stay on THIS stream:
+        # behind the weight-gradient stream's backlog of small split-K GEMMs (it runs ~2 ms late at this point)
+        # they would start only when that has drained; here the backlog drains beside them instead.
+        inline = os.environ.get("SHG_CONV_WGRAD_INLINE", "1") != "0"
         d1, part1 = K.bias_act_bwd(pre1, None, d_y1, ACT_GELU, want_dbias=True)
         _acc_vec(part1, b1)
-        with _WgradStream(x_cl, d1):
+        if inline:
             K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
-        E.grad_written(w1)
+            E.grad_written(w1)
+            K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+            E.grad_written(w2)
+        else:
+            with _WgradStream(y1p, d2):
+                K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+            E.grad_written(w2)
+            with _WgradStream(x_cl, d1):
+                K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
+            E.grad_written(w1)
         return None, None, None, None, None, None, None, None, None
 
 
