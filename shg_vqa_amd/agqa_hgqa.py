@@ -150,8 +150,9 @@ class AGQA:
                 rel_segment_ids=rel_seg, act_segment_ids=act_seg, hg_mask=b.get("hg_mask"))
             # the three losses are independent chains of small, latency-bound kernels (the Hungarian solver runs
             # 180 us on a fraction of the chip): the two set losses go to side streams, the BCE stays here
-            side = os.environ.get("SHG_LOSS_BRANCH", "1") != "0"
-            br_r, br_a = ops.Branch(2 if side else -1, rel_logit), ops.Branch(1 if side else -1, act_logit)
+            # (the prediction heads already ran on side stream 1, agqa_model.HGDecoder.forward: no wait for the main
+            # stream, which is busy with the hyper-graph cross encoder by now)
+            br_r = br_a = ops.Branch(1, rel_logit, act_logit, wait=not a.loss_hg_per_frame)   # (per-clip targets are built here)
             if a.loss_hg_per_frame:                  # one assignment problem per frame (matcher.py:62-80)
                 r_tgt, r_len, r_per = b["rel_triplets"].view(-1, self.num_rel), b["lengths"].view(-1), self.num_rel
                 a_tgt, a_len, a_per = b["act_tokens"].view(-1, self.num_act), b["act_lengths"].view(-1), self.num_act
@@ -164,8 +165,7 @@ class AGQA:
             with br_a:
                 as_, agrid, aq, at = ops.set_loss(act_logit, a_tgt, a_len, self.empty_weight_acts, a_per)
             bce = ops.bce_with_logits_times_c(hg_logit, b["target"])
-            br_r.join(rs, rgrid, rq, rt)
-            br_a.join(as_, agrid, aq, at)
+            br_r.join(rs, rgrid, rq, rt, as_, agrid, aq, at, rel_logit, act_logit)
             if self.world is not None:
                 rs, as_ = self.world.global_loss_sums2(rs, as_)
             rel_ce, act_ce = rs[0] / rs[1], as_[0] / as_[1]

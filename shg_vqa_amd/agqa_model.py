@@ -51,25 +51,34 @@ class HGDecoder(nn.Module):
         self.rel_decoder.apply(_init_bert_weights)
         self.action_decoder.apply(_init_bert_weights)
 
-    def forward(self, memory, rel_segment_ids, act_segment_ids):
+    def forward(self, memory, rel_segment_ids, act_segment_ids, defer_heads_join=False):
         B = memory.shape[0]
         dev = memory.device
 
-        def decode(emb, dec, head, seg, per):
+        def decode(emb, dec, seg, per):
             qpos = emb(seg)
             mask = rel_target_mask_device(self.num_situations, per, dev)
-            out = dec.forward_bf(torch.zeros_like(qpos), memory, qpos, mask)
-            return out, M.mlp_head(head, out)
+            return dec.forward_bf(torch.zeros_like(qpos), memory, qpos, mask)
 
         # the two decoders only share `memory`: the action decoder runs on a side stream beside the
         # relation decoder (both are chains of small launches that leave most of the GPU idle)
         branch = ops.Branch(1, memory, act_segment_ids)
         with branch:
-            act_out, act_preds = decode(self.action_query_embed, self.action_decoder, self.action_embed, act_segment_ids,
-                                        self.num_act)
-        rel_out, rel_preds = decode(self.relation_query_embed, self.rel_decoder, self.class_embed, rel_segment_ids,
-                                    self.num_rel)
-        branch.join(act_out, act_preds)
+            act_out = decode(self.action_query_embed, self.action_decoder, act_segment_ids, self.num_act)
+        rel_out = decode(self.relation_query_embed, self.rel_decoder, rel_segment_ids, self.num_rel)
+        branch.join(act_out)
+        # Both prediction heads (and later the two set losses, agqa_hgqa.forward_losses) stay on the side stream:
+        # the main chain goes straight on to the hyper-graph cross encoder, which only needs the decoder outputs.
+        # In backward autograd replays them there as well, beside the cross encoder's backward.
+        heads = ops.Branch(1, rel_out)
+        with heads:
+            act_preds = M.mlp_head(self.action_embed, act_out)
+            rel_preds = M.mlp_head(self.class_embed, rel_out)
+        if defer_heads_join:
+            self.heads_branch = heads        # AGQAModel.forward joins it before returning the predictions
+        else:
+            self.heads_branch = None
+            heads.join(rel_preds, act_preds)
         T = self.num_situations
         hg_in = torch.cat([act_out.view(B, T, -1, self.hid_dim), rel_out.view(B, T, -1, self.hid_dim)], dim=2)
         return rel_preds, act_preds, hg_in.view(B, -1, self.hid_dim)
@@ -191,10 +200,15 @@ class AGQAModel(nn.Module):
         else:
             lang_feats, lang_mask, memory, _ = attn[-1]
         # rel_tgt_mask / act_tgt_mask arguments are ignored like in the reference (agqa_model.py:220, :241)
-        rel_preds, act_preds, hg_in = self.hg_decoder(memory, rel_segment_ids, act_segment_ids)
+        rel_preds, act_preds, hg_in = self.hg_decoder(memory, rel_segment_ids, act_segment_ids, defer_heads_join=True)
         ops.join_deferred_branch(lang_feats, logit)      # the language stream: question features + the deferred x-layers
         B = memory.shape[0]
         hgm = hg_mask.view(B, -1) if (a.use_hg_mask and hg_mask is not None) else None
         x, attn = self.hgq_encoder(lang_feats, lang_mask, hg_in, hgm)
         hg_logit = M.mlp_head(self.logit_fc, x)
+        # the heads finished long ago (the cross encoder above is ~10x their work): this only orders later readers
+        hb, self.hg_decoder.heads_branch = self.hg_decoder.heads_branch, None
+        if hb is not None:
+            hb.main = torch.cuda.current_stream()
+            hb.join(rel_preds, act_preds)
         return logit, rel_preds, act_preds, hg_logit, attn

@@ -80,14 +80,16 @@ class Branch:
     the backward of the branch overlaps as well.  `inputs`: tensors produced on the main stream that the
     branch reads; call `.publish(*outs)` on the tensors the main stream consumes after `.join()`."""
 
-    def __init__(self, index, *inputs):
+    def __init__(self, index, *inputs, wait=True):
         self.side = engine().aux_stream(index)
         self.main = torch.cuda.current_stream() if self.side is not None else None
         self.inputs = inputs
+        self.wait = wait          # False: everything the block reads was produced on the side stream itself (or long ago)
 
     def __enter__(self):
         if self.side is not None:
-            self.side.wait_stream(self.main)
+            if self.wait:
+                self.side.wait_stream(self.main)
             for t in self.inputs:
                 if t is not None:
                     t.record_stream(self.side)
