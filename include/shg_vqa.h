@@ -185,17 +185,20 @@ int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype
 /* C = act(A . B + bias) with the activation in the epilogue and, when `pre` is given, the pre-activation
  * values A . B + bias written to pre [M, N] (row stride N, dtype_c) for the backward pass: BertIntermediate's
  * Linear + erf-GELU (modeling_capsbert.py:472-475, :127-133) and the heads' Linear + GELU (agqa_model.py:105-110)
- * as one kernel.  act: SHG_ACT_*. */
+ * as one kernel.  act: SHG_ACT_*.  p_drop > 0: dropout on the activation's output with the masks of shg_bias_act_fwd
+ * (seed_state / stream_id as there): the decoder's linear1 + ReLU + dropout (transformer.py:230).  shg_gemm_dact takes the
+ * same three arguments for the matching backward (mask applied to the incoming gradient, then act'). */
 int shg_gemm_act(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
                  int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor, int act,
-                 void* pre, void* stream);
+                 void* pre, float p_drop, const uint64_t* seed_state, uint64_t stream_id, void* stream);
 
 /* Input gradient through Linear + activation in one kernel:  dx[M,N] = (dy[M,K] . W[K,N]) * act'(pre[M,N]) and
  * dbias[n] += sum_m dx[m,n] (fp32 atomics; dbias may be null).  dy row stride lda, W stored [K, N] with row stride
  * ldb (the forward weight of the FOLLOWING Linear, [out = K, in = N]), pre contiguous [M, N]: the backward of
  * BertIntermediate's GELU (modeling_capsbert.py:472-475) folded into BertOutput.dense's input-gradient GEMM. */
 int shg_gemm_dact(const void* dy, const void* w, void* dx, const void* pre, float* dbias, int dtype, int64_t M, int64_t N,
-                  int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, void* stream);
+                  int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, float p_drop, const uint64_t* seed_state,
+                  uint64_t stream_id, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Conv3d with kernel (5,3,3), "valid" in T, zero padding 1 in H and W, as an implicit GEMM over a

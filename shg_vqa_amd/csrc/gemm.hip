@@ -271,6 +271,12 @@ template <typename TC> struct Epilogue {
     // (ld = N) the saved pre-activation, and csum[n] += sum_m C[m, n] (the bias gradient), by atomics
     const TC* gpre;
     float* csum;
+    // dropout on the activation's output (forward) / on the incoming gradient (gpre form), same counter-based masks
+    // as the stand-alone bias_act kernels: element index = m * N + n
+    uint32_t drop_thr;
+    float drop_scale;
+    const uint64_t* seed_state;
+    uint64_t stream_id;
 };
 
 __device__ __forceinline__ float act_grad_rt(float u, int act, bool fast) {
@@ -295,6 +301,7 @@ template <> struct RowWriter<bf16_t> {
     __device__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0) {
         float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const uint64_t dseed = ep.drop_thr ? dropout_seed(ep.seed_state, ep.stream_id) : 0;
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
             const int row = 8 * p + (lane >> 3), col = (lane & 7) * 8;
@@ -314,6 +321,7 @@ template <> struct RowWriter<bf16_t> {
                 bf16x8 o;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
+                    if (ep.drop_thr) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
                     u[r] *= act_grad_rt((float)gp[r], ep.act, true);
                     o[r] = (bf16_t)u[r];
                     csum8[r] += (float)o[r];
@@ -327,6 +335,12 @@ template <> struct RowWriter<bf16_t> {
                     const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(apply_act<true>(u[r], ep.act) + (float)old[r]);
+                } else if (ep.drop_thr) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float a = apply_act<true>(u[r], ep.act);
+                        o[r] = (bf16_t)(dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? a * ep.drop_scale : 0.f);
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (bf16_t)apply_act<true>(u[r], ep.act);
@@ -372,6 +386,7 @@ template <> struct RowWriter<float> {
             return;
         }
         float csum4[4] = {0.f, 0.f, 0.f, 0.f};
+        const uint64_t dseed = ep.drop_thr ? dropout_seed(ep.seed_state, ep.stream_id) : 0;
 #pragma unroll 2
         for (int p = 0; p < 16; ++p) {
             const int row = 4 * p + (lane >> 4), col = (lane & 15) * 4;
@@ -389,6 +404,7 @@ template <> struct RowWriter<float> {
                 const f32x4 gp = *reinterpret_cast<const f32x4*>(ep.gpre + m * N + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (ep.drop_thr) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
                     u[r] *= act_grad_rt(gp[r], ep.act, false);
                     csum4[r] += u[r];
                 }
@@ -397,6 +413,11 @@ template <> struct RowWriter<float> {
             }
             if (nv == 4 && ep.vec_ok) {
                 f32x4 o = {apply_act(u[0], ep.act), apply_act(u[1], ep.act), apply_act(u[2], ep.act), apply_act(u[3], ep.act)};
+                if (ep.drop_thr) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? o[r] * ep.drop_scale : 0.f;
+                }
                 if (ep.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
                 *reinterpret_cast<f32x4*>(dst) = o;
                 if (pre && (N % 4) == 0) *reinterpret_cast<f32x4*>(pre) = f32x4{u[0], u[1], u[2], u[3]};
@@ -999,7 +1020,8 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 static int gemm_entry(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
                       int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
-                      int accumulate, int act, void* pre, void* stream) {
+                      int accumulate, int act, void* pre, void* stream, float p_drop = 0.f,
+                      const uint64_t* seed_state = nullptr, uint64_t stream_id = 0) {
     if (!a || !b || !c) return fail_arg("gemm: null pointer");
     if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm: sizes must be positive");
     if ((dtype_ab != SHG_F32 && dtype_ab != SHG_BF16) || (dtype_c != SHG_F32 && dtype_c != SHG_BF16)) return fail_arg("gemm: bad dtype");
@@ -1023,12 +1045,15 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
     const int vlen = dtype_c == SHG_F32 ? 4 : 8;      // elements per 16-byte output vector
     const int vec_ok = (ldc % vlen == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0) &&
                        (!pre || ((N % vlen == 0) && al16(pre)));
+    if (p_drop > 0.f && !vec_ok) return fail_arg("gemm: the dropout epilogue needs 16-byte aligned rows of C");
+    const uint32_t dthr = dropout_threshold(p_drop);
+    const float dscale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     if (dtype_c == SHG_F32) {
-        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (float*)pre, 0};
+        Epilogue<float> ep{(float*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (float*)pre, 0, nullptr, nullptr, dthr, dscale, seed_state, stream_id};
         return dtype_ab == SHG_F32 ? gemm_dispatch<float, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st)
                                    : gemm_dispatch<bf16_t, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
     }
-    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0};
+    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0, nullptr, nullptr, dthr, dscale, seed_state, stream_id};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
 }
 
@@ -1039,29 +1064,42 @@ extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias
                       nullptr, stream);
 }
 
+static int drop_args_ok(float p_drop, const uint64_t* seed_state, int64_t N) {
+    if (p_drop < 0.f || p_drop >= 1.f) return fail_arg("gemm: p_drop must be in [0, 1)");
+    if (p_drop > 0.f && !seed_state) return fail_arg("gemm: dropout needs seed_state");
+    if (p_drop > 0.f && (N % 8)) return fail_arg("gemm: the dropout epilogue needs N % 8 == 0");
+    return 0;
+}
+
 extern "C" int shg_gemm_dact(const void* dy, const void* w, void* dx, const void* pre, float* dbias, int dtype, int64_t M,
-                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, void* stream) {
+                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, float p_drop,
+                             const uint64_t* seed_state, uint64_t stream_id, void* stream) {
     if (!dy || !w || !dx || !pre) return fail_arg("gemm_dact: null pointer");
     if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm_dact: sizes must be positive");
     if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("gemm_dact: bad dtype");
     if (act < 0 || act > 2) return fail_arg("gemm_dact: bad activation");
+    if (int e = drop_args_ok(p_drop, seed_state, N)) return e;
     const int epc = dtype == SHG_BF16 ? 8 : 4;
     if (N % 8 || K % epc) return fail_arg("gemm_dact: N must be a multiple of 8 and K of the 16-byte chunk");
     if (!al16(dy) || !al16(w) || !al16(dx) || !al16(pre)) return fail_arg("gemm_dact: pointers must be 16-byte aligned");
     if (lda % epc || ldb % epc || ldc % epc || lda < K || ldb < N || ldc < N) return fail_arg("gemm_dact: bad leading dimension");
     hipStream_t st = (hipStream_t)stream;
+    const uint32_t thr = dropout_threshold(p_drop);
+    const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     if (dtype == SHG_F32) {
-        Epilogue<float> ep{(float*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const float*)pre, dbias};
+        Epilogue<float> ep{(float*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const float*)pre, dbias, thr, scale, seed_state, stream_id};
         return gemm_dispatch<float, float>(dy, w, ep, M, N, K, lda, ldb, 1, 0, st);
     }
-    Epilogue<bf16_t> ep{(bf16_t*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const bf16_t*)pre, dbias};
+    Epilogue<bf16_t> ep{(bf16_t*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const bf16_t*)pre, dbias, thr, scale, seed_state, stream_id};
     return gemm_dispatch<bf16_t, bf16_t>(dy, w, ep, M, N, K, lda, ldb, 1, 0, st);
 }
 
 extern "C" int shg_gemm_act(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
-                            int act, void* pre, void* stream) {
-    return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 0, act, pre, stream);
+                            int act, void* pre, float p_drop, const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+    if (int e = drop_args_ok(p_drop, seed_state, N)) return e;
+    return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 0, act, pre, stream, p_drop,
+                      seed_state, stream_id);
 }
 
 extern "C" int64_t shg_conv3d_k533_workspace_bytes(int B, int T, int H, int W) {

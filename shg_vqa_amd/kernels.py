@@ -289,8 +289,9 @@ def attention_bwd(q, k, v, o, d_o, lse, dq, dk, dv, heads, mask_kind=MASK_NONE, 
 
 
 # ------------------------------------------------------------------------------------------------
-def gemm_act(a, b, out, bias, act, pre=None):
-    """out = act(a . b^T + bias) in one kernel (a [M,K], b [N,K]); pre [M,N] receives a . b^T + bias."""
+def gemm_act(a, b, out, bias, act, pre=None, p_drop=0.0, seed_state=None, stream_id=0):
+    """out = dropout(act(a . b^T + bias)) in one kernel (a [M,K], b [N,K]); pre [M,N] receives a . b^T + bias."""
+    _dev(a, b, out, bias, pre, seed_state)
     m, k = a.shape
     n = b.shape[0]
     _need(a.dtype == b.dtype and b.shape[1] == k and out.shape == (m, n) and out.stride(1) == 1 and a.stride(1) == 1
@@ -298,23 +299,25 @@ def gemm_act(a, b, out, bias, act, pre=None):
     if pre is not None:
         _need(pre.shape == (m, n) and pre.is_contiguous() and pre.dtype == out.dtype, "pre must be contiguous [M, N] of out's dtype")
     _f32vec(bias, n, "bias")
+    _need(p_drop == 0.0 or seed_state is not None, "dropout needs seed_state")
     _lib.call("shg_gemm_act", a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), _dt(a), _dt(out), m, n, k, a.stride(0),
-              b.stride(0), out.stride(0), 1, 1, int(act), _p(pre), _stream())
+              b.stride(0), out.stride(0), 1, 1, int(act), _p(pre), float(p_drop), _p(seed_state), int(stream_id), _stream())
     return out
 
 
-def gemm_dact(dy, w, dx, pre, dbias, act):
-    """dx = (dy . w) * act'(pre), dbias += column sums of dx.  dy [M,K]; w [K,N] (a forward weight [out, in]);
-    pre / dx [M,N]; dbias fp32 [N] or None."""
-    _dev(dy, w, dx, pre, dbias)
+def gemm_dact(dy, w, dx, pre, dbias, act, p_drop=0.0, seed_state=None, stream_id=0):
+    """dx = dropout_mask(dy . w) * act'(pre), dbias += column sums of dx.  dy [M,K]; w [K,N] (a forward weight
+    [out, in]); pre / dx [M,N]; dbias fp32 [N] or None.  The mask is the one gemm_act applied in the forward."""
+    _dev(dy, w, dx, pre, dbias, seed_state)
     m, k = dy.shape
     n = w.shape[1]
     _need(w.shape[0] == k and dx.shape == (m, n) and pre.shape == (m, n), "gemm_dact: shape mismatch")
     _need(dy.dtype == w.dtype == dx.dtype == pre.dtype, "gemm_dact: one dtype for all operands")
     _need(dy.stride(1) == 1 and w.stride(1) == 1 and dx.stride(1) == 1 and pre.is_contiguous(), "gemm_dact: layout")
     _f32vec(dbias, n, "dbias")
+    _need(p_drop == 0.0 or seed_state is not None, "dropout needs seed_state")
     _lib.call("shg_gemm_dact", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), pre.data_ptr(), _p(dbias), _dt(dy), m, n, k,
-              dy.stride(0), w.stride(0), dx.stride(0), int(act), _stream())
+              dy.stride(0), w.stride(0), dx.stride(0), int(act), float(p_drop), _p(seed_state), int(stream_id), _stream())
     return dx
 
 

@@ -831,13 +831,10 @@ class _FFNSublayer(torch.autograd.Function):
         pi, seed_i, sid_i = _drop_args(P.p_inner)
         po, seed_o, sid_o = _drop_args(P.p_out)
         pre = torch.empty((rows, F), dtype=dt, device=dev)
-        fused = pi == 0.0
-        if fused:                                   # Linear + bias + activation in the GEMM epilogue
-            h = torch.empty((rows, F), dtype=dt, device=dev)
-            K.gemm_act(x2, E.operand(P.w1), h, P.b1._shg_store.view(-1), P.act, pre)
-        else:
-            K.gemm(x2, E.operand(P.w1), pre, None, True, True)
-            h = K.bias_act_fwd(pre, P.b1._shg_store.view(-1), P.act, pi, seed_i, sid_i)
+        h = torch.empty((rows, F), dtype=dt, device=dev)
+        # Linear + bias + activation (+ the decoder's inner dropout) in the GEMM epilogue
+        K.gemm_act(x2, E.operand(P.w1), h, P.b1._shg_store.view(-1), P.act, pre, pi, seed_i, sid_i)
+        fused = True
         t = torch.empty((rows, H), dtype=dt, device=dev)
         K.gemm(h, E.operand(P.w2), t, None, True, True)
         y, z, mean, rstd = K.ln_fwd(t, P.b2._shg_store.view(-1), x2, P.gamma._shg_store, P.beta._shg_store, P.eps,
@@ -858,17 +855,11 @@ class _FFNSublayer(torch.autograd.Function):
         _finish_ln_grads(dg, db, dbi, P.gamma, P.beta, P.b2)
         _wgrad(dt_, h, P.w2, None)
         want_b1 = P.b1._shg_grad is not None
-        if fused:                                   # activation backward + bias gradient in the dgrad GEMM's epilogue
-            dpre = torch.empty_like(h)
-            K.gemm_dact(dt_, E.operand(P.w2), dpre, pre, P.b1._shg_grad.view(-1) if want_b1 else None, P.act)
-            if want_b1:
-                E.grad_written(P.b1)
-        else:
-            dh = torch.empty_like(h)
-            K.gemm(dt_, E.operand(P.w2), dh, None, True, False)
-            dpre, part = K.bias_act_bwd(pre, P.b1._shg_store.view(-1), dh, P.act, pi, seed_i, sid_i, want_dbias=want_b1)
-            if want_b1:
-                _acc_vec(part, P.b1)
+        # activation (and inner dropout) backward + bias gradient in the dgrad GEMM's epilogue
+        dpre = torch.empty_like(h)
+        K.gemm_dact(dt_, E.operand(P.w2), dpre, pre, P.b1._shg_grad.view(-1) if want_b1 else None, P.act, pi, seed_i, sid_i)
+        if want_b1:
+            E.grad_written(P.b1)
         _wgrad(dpre, x2, P.w1, None)
         if not ctx.needs_input_grad[0]:
             return None, None, None

@@ -676,3 +676,40 @@ def test_hungarian_per_clip_matches_oracle_on_model_sized_problems(K, dtype):
             n = int(lens[b])
             assert torch.equal(oq[b, :n].cpu(), qi) and torch.equal(ot[b, :n].cpu(), ti), (dtype, B, Q, b)
             assert (oq[b, n:] == -1).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_dropout_uses_the_masks_of_the_standalone_kernels(K, dtype):
+    """Linear + ReLU + dropout as one kernel (transformer.py:230) and its backward in the dgrad epilogue draw the same
+    counter-based masks as shg_bias_act_fwd / bwd: fused and unfused paths must agree element for element."""
+    gen = torch.Generator().manual_seed(41)
+    seed = torch.tensor([77, 3], dtype=torch.int64, device=DEV)
+    for (M, N, Kd) in [(4096, 2048, 768), (200, 264, 72)]:
+        x = torch.randn(M, Kd, generator=gen).to(dtype).to(DEV)
+        w = (torch.randn(N, Kd, generator=gen) / math.sqrt(Kd)).to(dtype).to(DEV)
+        bias = torch.randn(N, generator=gen).to(DEV)
+        p, sid = 0.15, 9
+        # forward: fused vs GEMM (+ bias, pre-activation out) followed by the stand-alone activation + dropout kernel
+        out = torch.empty(M, N, dtype=dtype, device=DEV)
+        pre = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm_act(x, w, out, bias, 2, pre, p, seed, sid)
+        ref = K.bias_act_fwd(pre, None, 2, p, seed, sid)
+        if dtype == torch.float32:
+            assert torch.equal(out, ref)
+        else:                                  # the fused epilogue rounds once (fp32 accumulator -> bf16), the two-pass path twice
+            _assert_close(out, ref, dtype)
+            assert torch.equal(out == 0, ref == 0)
+        kept = (out != 0).float().mean().item() / max((pre > 0).float().mean().item(), 1e-6)
+        assert abs(kept - (1 - p)) < 0.02, kept
+        # backward: fused dgrad epilogue vs GEMM followed by the stand-alone backward kernel
+        dy = torch.randn(M, 96, generator=gen).to(dtype).to(DEV)
+        w2 = (torch.randn(96, N, generator=gen) / 10).to(dtype).to(DEV)
+        dx = torch.empty(M, N, dtype=dtype, device=DEV)
+        db = torch.zeros(N, device=DEV)
+        K.gemm_dact(dy, w2, dx, pre, db, 2, p, seed, sid)
+        dh = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm(dy, w2, dh, None, True, False)
+        dref, _ = K.bias_act_bwd(pre, None, dh, 2, p, seed, sid, want_dbias=False)
+        _assert_close(dx, dref, dtype)
+        assert torch.equal(dx == 0, dref == 0)            # identical masks (and ReLU gates)
+        assert torch.allclose(db.double().cpu(), dx.double().cpu().sum(0), rtol=1e-4, atol=2e-3 * math.sqrt(M))
