@@ -51,7 +51,7 @@ class HGDecoder(nn.Module):
         self.rel_decoder.apply(_init_bert_weights)
         self.action_decoder.apply(_init_bert_weights)
 
-    def forward(self, memory, rel_segment_ids, act_segment_ids, defer_heads_join=False):
+    def forward(self, memory, rel_segment_ids, act_segment_ids):
         B = memory.shape[0]
         dev = memory.device
 
@@ -74,8 +74,8 @@ class HGDecoder(nn.Module):
         with heads:
             act_preds = M.mlp_head(self.action_embed, act_out)
             rel_preds = M.mlp_head(self.class_embed, rel_out)
-        if defer_heads_join:
-            self.heads_branch = heads        # AGQAModel.forward joins it before returning the predictions
+        if getattr(self, "defer_heads_join", False):    # set by AGQAModel.forward, which joins before it returns
+            self.heads_branch = heads
         else:
             self.heads_branch = None
             heads.join(rel_preds, act_preds)
@@ -200,7 +200,11 @@ class AGQAModel(nn.Module):
         else:
             lang_feats, lang_mask, memory, _ = attn[-1]
         # rel_tgt_mask / act_tgt_mask arguments are ignored like in the reference (agqa_model.py:220, :241)
-        rel_preds, act_preds, hg_in = self.hg_decoder(memory, rel_segment_ids, act_segment_ids, defer_heads_join=True)
+        self.hg_decoder.defer_heads_join = True
+        try:
+            rel_preds, act_preds, hg_in = self.hg_decoder(memory, rel_segment_ids, act_segment_ids)
+        finally:
+            self.hg_decoder.defer_heads_join = False
         ops.join_deferred_branch(lang_feats, logit)      # the language stream: question features + the deferred x-layers
         B = memory.shape[0]
         hgm = hg_mask.view(B, -1) if (a.use_hg_mask and hg_mask is not None) else None
