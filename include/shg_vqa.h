@@ -237,9 +237,11 @@ int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int
  *   shg_sumsq: partial[blocks] -> norm_sq[0] (fp32 accumulate in fp64 inside) of grad[0..n)
  *   state: step_state[0] = number of updates already applied (int64, device); incremented by the kernel.
  *   shadow (may be NULL): bf16 copy of the updated parameters, written in the same pass.
+ *   bump_step: bit 0 = increment step_state afterwards; bit 1 = also zero the gradient in this pass (the
+ *   optimizer.zero_grad() of the next step, agqaHGQA.py:387, without a separate sweep over the arena).
  */
 int shg_sumsq(const float* x, int64_t n, double* partial, int n_partial, float* out_norm, void* stream);
-int shg_bertadam_arena(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+int shg_bertadam_arena(float* param, float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
                        const float* grad_norm, float max_norm, float lr, float warmup, int64_t t_total,
                        float b1, float b2, float eps, float weight_decay, int64_t* step_state, int bump_step,
                        void* stream);

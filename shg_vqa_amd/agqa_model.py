@@ -167,6 +167,11 @@ class AGQAModel(nn.Module):
         canon = {n for n, _ in self.named_parameters()}
         groups = [g for g in groups if all(n in canon for n in g)]
         E.adopt(self, self.active_parameter_names(), groups)
+        # the step's first consumer of parameters (BertAdam.step keeps their update on the main stream)
+        E.first_params = None
+        if not self.args.task_q:
+            c1 = self.lxrt_encoder.model.bert.encoder.visn_fc.conv[1]
+            E.first_params = [c1.weight, c1.bias]
         return self
 
     def train(self, mode=True):
@@ -179,6 +184,7 @@ class AGQAModel(nn.Module):
                 act_segment_ids=None, act_tgt_mask=None, hg_mask=None, rel_tgt_ids=None, act_tgt_ids=None):
         a = self.args
         if a.task_q:
+            engine().wait_params_ready()
             feats, x, attn = self.bert_encoder((input_ids, input_masks, segment_ids))
             return M.mlp_head(self.logit_fc, x), attn
         feat = self.vid_encoder.encode(feat)

@@ -45,12 +45,12 @@ __device__ __forceinline__ double warmup_linear(double x, double warmup) {
     return y > 0.0 ? y : 0.0;
 }
 
-__global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        bf16_t* __restrict__ shadow, int64_t n,
                                                        const float* __restrict__ grad_norm, float max_norm, float lr,
                                                        float warmup, int64_t t_total, float b1, float b2, float eps,
-                                                       float wd, const int64_t* __restrict__ step_state, int mode) {
+                                                       float wd, const int64_t* __restrict__ step_state, int mode, int zero_g) {
     float clip = 1.f;
     if (grad_norm && max_norm > 0.f) clip = fminf(max_norm / (grad_norm[0] + 1e-6f), 1.f);
     double lr_d = (double)lr;
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
         }
     };
     f32x4* p4 = reinterpret_cast<f32x4*>(p);
-    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    f32x4* g4 = reinterpret_cast<f32x4*>(g);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4* m4 = reinterpret_cast<f32x4*>(m);
     f32x4* v4 = reinterpret_cast<f32x4*>(v);
     bf16x4* s4 = reinterpret_cast<bf16x4*>(shadow);
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
         update(pb, gb, mb, vb, sb);
         __builtin_nontemporal_store(pa, p4 + i); __builtin_nontemporal_store(ma, m4 + i); __builtin_nontemporal_store(va, v4 + i);
         __builtin_nontemporal_store(pb, p4 + k); __builtin_nontemporal_store(mb, m4 + k); __builtin_nontemporal_store(vb, v4 + k);
+        if (zero_g) { g4[i] = zero4; g4[k] = zero4; }    // next step's weight-gradient GEMMs accumulate from zero
         if (shadow) { s4[i] = sa; s4[k] = sb; }           // the bf16 operands are read again by the next step's GEMMs
     }
     for (; i < n4; i += stride) {
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
         update(pa, ga, ma, va, sa);
         p4[i] = pa; m4[i] = ma; v4[i] = va;
         if (shadow) s4[i] = sa;
+        if (zero_g) g4[i] = zero4;
     }
     if (blockIdx.x == 0)
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, co
             const float pp = p[i] - lr_t * (mm / (sqrtf(vv) + eps) + wd * p[i]);
             p[i] = pp;
             if (shadow) shadow[i] = (bf16_t)pp;
+            if (zero_g) g[i] = 0.f;
         }
 }
 
@@ -137,7 +141,7 @@ extern "C" int shg_sumsq(const float* x, int64_t n, double* partial, int n_parti
     return check_launch("sumsq");
 }
 
-extern "C" int shg_bertadam_arena(float* param, const float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
+extern "C" int shg_bertadam_arena(float* param, float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
                                   const float* grad_norm, float max_norm, float lr, float warmup, int64_t t_total,
                                   float b1, float b2, float eps, float weight_decay, int64_t* step_state, int bump_step,
                                   void* stream) {
@@ -153,9 +157,9 @@ extern "C" int shg_bertadam_arena(float* param, const float* grad, float* m, flo
         static const int64_t adam_blocks = []() { const char* e = getenv("SHG_BERTADAM_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)16384; }();   // measured: 2 048 .. 8 192 blocks 4.3-4.5 TB/s, 16 384 4.8
         const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, adam_blocks);
         hipLaunchKernelGGL(bertadam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, m, v, (bf16_t*)shadow_bf16,
-                           n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state, adam_mode);
+                           n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state, adam_mode, (bump_step >> 1) & 1);
     }
-    if (bump_step) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, st, step_state, (int64_t)1);
+    if (bump_step & 1) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, st, step_state, (int64_t)1);
     return check_launch("bertadam_arena");
 }
 

@@ -64,6 +64,12 @@ class Engine:
         # stream, off the critical path, until AGQAModel.forward joins it (ops.Branch.reenter / join)
         self.defer_x_layers = False
         self.deferred_branch = None
+        self.grad_dirty = False           # gradients written since the arena was last zeroed
+        self.params_ready_event = None
+        # set per call by AGQA.train_step(overlap_update=True): the caller then waits (wait_params_ready / a device
+        # synchronisation / the next train_step) before it reads parameters on another stream
+        self.lazy_adam = False
+        self.first_params = None          # the parameters the step reads first (conv1's weight, bias): updated on the main stream
         self.kernel_events = None        # bench.py: list collecting (start, end) events of the dominant kernel
         self.pending_clip = None
 
@@ -143,6 +149,7 @@ class Engine:
     def refresh_shadows(self):
         """bf16 operand copies of every weight (after loading a checkpoint / initialisation)."""
         from . import kernels as K
+        self.wait_params_ready()
         K.cast_f32(self.param_arena, self.shadow_arena)
 
     def operand(self, p):
@@ -178,10 +185,26 @@ class Engine:
             cur.wait_stream(s)
 
     def zero_grad(self):
-        if self.grad_arena is not None:
+        """The optimiser pass leaves the gradient arena zeroed (BertAdam.step): the sweep is only needed when
+        something has written gradients since (grad_dirty)."""
+        if self.grad_arena is not None and self.grad_dirty:
+            self.wait_params_ready()
             self.grad_arena.zero_()
+            self.grad_dirty = False
+
+    def wait_params_ready(self):
+        """BertAdam.step may leave the update of everything but the first convolution's weight running on a side
+        stream (it overlaps the next step's conv1, which is compute-bound while the update is HBM-bound).  Whoever
+        reads parameters, gradients or the step counters on the current stream calls this first."""
+        ev, self.params_ready_event = self.params_ready_event, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def mark_grads_dirty(self):
+        self.grad_dirty = True
 
     def grad_written(self, p):
+        self.grad_dirty = True
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(p._shg_off, p._shg_numel)
 

@@ -433,7 +433,7 @@ def grad_norm(flat_grad, partial=None):
 
 
 def bertadam_arena(param, grad, m, v, shadow, grad_norm_t, max_norm, lr, warmup, t_total, step_state, b1=0.9, b2=0.999,
-                   eps=1e-6, weight_decay=0.01, bump_step=True):
+                   eps=1e-6, weight_decay=0.01, bump_step=True, zero_grad=False):
     _dev(param, grad, m, v, shadow, grad_norm_t, step_state)
     n = param.numel()
     for t, nm in ((param, "param"), (grad, "grad"), (m, "m"), (v, "v")):
@@ -443,7 +443,7 @@ def bertadam_arena(param, grad, m, v, shadow, grad_norm_t, max_norm, lr, warmup,
     _need(step_state.dtype == torch.int64 and step_state.numel() >= 1, "step_state int64")
     _lib.call("shg_bertadam_arena", param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), _p(shadow), n,
               _p(grad_norm_t), float(max_norm), float(lr), float(warmup), int(t_total), float(b1), float(b2), float(eps),
-              float(weight_decay), step_state.data_ptr(), 1 if bump_step else 0, _stream())
+              float(weight_decay), step_state.data_ptr(), (1 if bump_step else 0) | (2 if zero_grad else 0), _stream())
 
 
 def add_i64(t, delta):

@@ -563,7 +563,10 @@ class NoCapsModel(BertPreTrainedModel):
         ext = additive_mask(attention_mask, input_ids)
         vmask = visual_feats[1]                      # the "boxes" slot carries the visual 0/1 mask, mc:1836
         ext_v = additive_mask(vmask, input_ids) if vmask is not None else None
-        emb = self.embeddings(input_ids, token_type_ids)
+        # the question embeddings only feed the language layers: same side stream (no parameter is read on the main
+        # stream before conv1, see BertAdam.step)
+        with ops.Branch(2, input_ids, token_type_ids):
+            emb = self.embeddings(input_ids, token_type_ids)
         lang, visn, probs = self.encoder(emb, ext, visn_feats=visual_feats, visn_attention_mask=ext_v)
         with ops.deferred_branch():                  # (the x-layers' stream, when they were deferred)
             pooled = self.pooler(visn, lang)

@@ -421,6 +421,7 @@ def conv1_forward(feat, w1, b1, bufs=None):
     if evs is not None:
         e1.record()
         evs.append((e0, e1))
+    E.wait_params_ready()              # conv1's own weight / bias were updated on this stream; everything else follows here
     return x_cl, y1p, pre1
 
 

@@ -7,6 +7,10 @@ from . import kernels as K
 from .engine import engine
 
 
+def _round8(n):
+    return (n + 7) // 8 * 8
+
+
 def warmup_linear(x, warmup=0.002):
     """optimization.py:38-43."""
     if x < warmup:
@@ -50,13 +54,42 @@ class BertAdam(torch.optim.Optimizer):
             raise RuntimeError("BertAdam needs the parameters to live in the engine arenas (Engine.adopt)")
         g = self.param_groups[0]
         E.join_side_streams()
+        E.wait_params_ready()
         norm, max_norm = getattr(E, "pending_clip", None) or (None, 0.0)
         E.pending_clip = None
         n = E.n_active
-        shadow = E.shadow_arena[:n]
-        # warmup < 0 means "no warm-up" in the reference (schedule still applies); map to the kernel's contract
-        K.bertadam_arena(E.param_arena[:n], E.grad_arena, E.m_arena, E.v_arena, shadow, norm, max_norm, g["lr"],
-                         g["warmup"], g["t_total"], E.step_state, g["b1"], g["b2"], g["e"], g["weight_decay"],
-                         bump_step=True)
-        K.add_i64(E.seed_state[1:], 1)        # next step -> fresh dropout masks (also under graph replay)
+
+        def update(lo, hi, bump):
+            if hi > lo:
+                # warmup < 0 means "no warm-up" in the reference (schedule still applies); map to the kernel's contract
+                K.bertadam_arena(E.param_arena[lo:hi], E.grad_arena[lo:hi], E.m_arena[lo:hi], E.v_arena[lo:hi],
+                                 E.shadow_arena[lo:hi], norm, max_norm, g["lr"], g["warmup"], g["t_total"], E.step_state,
+                                 g["b1"], g["b2"], g["e"], g["weight_decay"], bump_step=bump, zero_grad=True)
+
+        first = E.first_params
+        side = None
+        if E.lazy_adam and first and not torch.cuda.is_current_stream_capturing():
+            lo = min(p._shg_off for p in first)
+            hi = min(n, _round8(max(p._shg_off + p._shg_numel for p in first)))
+            if hi - lo <= sum(_round8(p._shg_numel) for p in first) and all(p._shg_grad is not None for p in first):
+                side = E.aux_stream(2)                      # (the parameters must sit back to back in the arena)
+        if side is None:
+            update(0, n, True)
+            K.add_i64(E.seed_state[1:], 1)    # next step -> fresh dropout masks (also under graph replay)
+        else:
+            # The step's first consumer of parameters is conv1 (2 ms, bound by the matrix cores): its weight and bias are
+            # updated here, everything else on a side stream, where the HBM-bound sweep overlaps the next step's conv1.
+            main = torch.cuda.current_stream()
+            update(lo, hi, False)             # alone on the chip first: it gates the next step's conv1
+            done_main = torch.cuda.Event()
+            done_main.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(done_main)    # (also orders it behind the gradient norm and the joined weight gradients,
+                update(0, lo, False)          #  and every update kernel reads the step counter before it is bumped)
+                update(hi, n, True)
+                K.add_i64(E.seed_state[1:], 1)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            E.params_ready_event = ev
+        E.grad_dirty = False
         return None

@@ -356,3 +356,30 @@ def test_per_clip_matching_losses_vs_oracle(golden_dir):
     out["total"].backward()
     engine().join_side_streams()
     assert torch.isfinite(engine().grad_arena).all() and engine().grad_arena.abs().max() > 0
+
+
+def test_overlapped_optimizer_update_gives_the_same_parameters():
+    """train_step(overlap_update=True) leaves BertAdam's sweep over everything but conv1's weight / bias on a side stream
+    (it overlaps the next step's conv1) and zeroes the gradients in the same pass: three steps must end bit-identical to
+    the plain schedule (dropout off; the split changes where kernels run, not what they compute)."""
+    from shg_vqa_amd.engine import engine
+    res = []
+    for overlap in (False, True):
+        tr = _build(torch.bfloat16)
+        from oracle import shg_ref
+        cfg = shg_ref.Cfg()
+        batches = [_device_batch(shg_ref.synthetic_batch(2, cfg, seed=50 + i)) for i in range(3)]
+        tr.model.eval()                              # dropout off (train_step switches the engine flag back on: force p = 0)
+        for m in tr.model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        for b in batches:
+            tr.train_step(b, overlap_update=overlap)
+        engine().wait_params_ready()
+        torch.cuda.synchronize()
+        res.append((engine().param_arena.clone(), engine().grad_arena.clone(), int(engine().step_state.item())))
+    (p0, g0, s0), (p1, g1, s1) = res
+    assert s0 == s1 == 3
+    assert (g0 == 0).all() and (g1 == 0).all()          # the optimiser pass leaves the gradient arena zeroed
+    # fp32 atomics in the split-K weight gradients / column sums make two runs differ in the last bits
+    assert torch.allclose(p0, p1, rtol=0, atol=2e-6), (p0 - p1).abs().max()
