@@ -491,16 +491,26 @@ class NoCapsEncoder(nn.Module):
 
     def forward(self, lang_feats, lang_attention_mask, visn_feats, visn_attention_mask=None,
                 output_all_attention_masks=False):
-        # the language layers (tiny launches) run on a side stream beside the conv stack + relation layers
-        branch = ops.Branch(2, lang_feats, lang_attention_mask)
+        # The language layers (tiny launches) run on a side stream beside the conv stack + relation layers.  The fork
+        # point is here (the side stream waits for what the main stream holds NOW), but their kernels are issued AFTER the
+        # relation layers': autograd replays nodes in reverse creation order, and the language backward - ready as soon
+        # as the hyper-graph encoder's backward is done - must not queue behind the conv stack's backward, where it would
+        # crawl beside the chip-filling conv weight gradients and hold up the optimiser (measured: ~1 ms per step).
+        # lang_feats may be a zero-argument callable producing the embeddings (NoCapsModel.forward), issued there too.
+        branch = ops.Branch(2, lang_attention_mask)
         with branch:
-            for layer in self.layer:
-                lang_feats, _ = layer(lang_feats, lang_attention_mask)
-        lang_out = lang_feats
+            pass
         visn_feats, _ = self.visn_fc(visn_feats)
         for layer in self.r_layers:
             visn_feats, _ = layer(visn_feats, visn_attention_mask)
         visn_out = visn_feats
+        branch.wait = False
+        with branch:
+            if callable(lang_feats):
+                lang_feats = lang_feats()
+            for layer in self.layer:
+                lang_feats, _ = layer(lang_feats, lang_attention_mask)
+        lang_out = lang_feats
         E = engine()
         if E.defer_x_layers and branch.side is not None and E.deferred_branch is None:
             # --taskHGQA: nothing on the loss path reads the x-layers' output; they continue on the language
@@ -563,11 +573,10 @@ class NoCapsModel(BertPreTrainedModel):
         ext = additive_mask(attention_mask, input_ids)
         vmask = visual_feats[1]                      # the "boxes" slot carries the visual 0/1 mask, mc:1836
         ext_v = additive_mask(vmask, input_ids) if vmask is not None else None
-        # the question embeddings only feed the language layers: same side stream (no parameter is read on the main
-        # stream before conv1, see BertAdam.step)
-        with ops.Branch(2, input_ids, token_type_ids):
-            emb = self.embeddings(input_ids, token_type_ids)
-        lang, visn, probs = self.encoder(emb, ext, visn_feats=visual_feats, visn_attention_mask=ext_v)
+        # the question embeddings only feed the language layers: the encoder issues them on that side stream (no
+        # parameter is read on the main stream before conv1, see BertAdam.step)
+        lang, visn, probs = self.encoder(lambda: self.embeddings(input_ids, token_type_ids), ext, visn_feats=visual_feats,
+                                         visn_attention_mask=ext_v)
         with ops.deferred_branch():                  # (the x-layers' stream, when they were deferred)
             pooled = self.pooler(visn, lang)
         return (lang, visn), pooled, probs

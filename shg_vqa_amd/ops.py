@@ -108,6 +108,7 @@ class Branch:
         if self.side is not None:
             self.main = torch.cuda.current_stream()
             self.inputs = inputs
+            self.wait = True
         return self
 
     def join(self, *outs):

@@ -83,6 +83,8 @@ class BertAdam(torch.optim.Optimizer):
             update(lo, hi, False)             # alone on the chip first: it gates the next step's conv1
             done_main = torch.cuda.Event()
             done_main.record(main)
+            if norm is not None:
+                norm.record_stream(side)      # read by the side stream's kernels after this function has dropped it
             with torch.cuda.stream(side):
                 side.wait_event(done_main)    # (also orders it behind the gradient norm and the joined weight gradients,
                 update(0, lo, False)          #  and every update kernel reads the step counter before it is bumped)
