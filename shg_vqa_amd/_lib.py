@@ -84,10 +84,32 @@ def exported_names():
     return sorted(_SIGNATURES)
 
 
+try:                                     # host-side trampoline (csrc_host/_fastcall.c, built by build.py); optional
+    from . import _fastcall as _fast
+except ImportError:                      # pragma: no cover
+    _fast = None
+_FAST = {}                               # name -> (function address, signature bytes)
+_SIG_CHAR = {c_void_p: "p", c_int: "i", c_int64: "l", c_float: "f", c_uint64: "u"}
+
+
+def _fast_entry(name):
+    h = lib()
+    args, ret = _SIGNATURES[name]
+    if ret is not c_int or len(args) > 30 or sum(a is c_float for a in args) > 8:
+        ent = None
+    else:
+        ent = (ctypes.cast(getattr(h, name), c_void_p).value, "".join(_SIG_CHAR[a] for a in args).encode())
+    _FAST[name] = ent
+    return ent
+
+
 def call(name, *args):
     """Calls an int-returning entry point and raises ShgError on a non-zero status."""
-    fn = getattr(lib(), name)
-    rc = fn(*args)
+    if _fast is not None:
+        ent = _FAST.get(name) or _fast_entry(name)
+        rc = _fast.call(ent[0], ent[1], *args) if ent is not None else getattr(lib(), name)(*args)
+    else:
+        rc = getattr(lib(), name)(*args)
     if rc != 0:
         msg = lib().shg_last_error_string()
         raise ShgError("%s failed (rc=%d): %s" % (name, rc, msg.decode() if msg else ""))

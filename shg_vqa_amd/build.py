@@ -56,9 +56,27 @@ def build(force=False, verbose=False):
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n%s" % res.stderr[-4000:])
+    _build_fastcall()
     if verbose:
         print("built", LIB)
     return LIB
+
+
+def _build_fastcall():
+    """Host-side CPython extension (csrc_host/_fastcall.c): low-overhead trampoline into the C ABI; optional - without
+    it _lib.call goes through ctypes."""
+    import sysconfig
+    src = os.path.join(HERE, "csrc_host", "_fastcall.c")
+    out = os.path.join(HERE, "_fastcall" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    inc = sysconfig.get_paths()["include"]
+    if not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    res = subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-I" + inc, "-o", out, src], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("gcc failed for _fastcall.c:\n%s" % res.stderr[-2000:])
+    return out
 
 
 if __name__ == "__main__":

@@ -152,8 +152,8 @@ def colsum_finish_multi(partials, outs):
     _need(1 <= n <= 4 and len(outs) == n, "1..4 (partial, out) pairs")
     n_partials, cols = partials[0].shape
     arr = ctypes.c_void_p * n
-    _lib.call("shg_colsum_finish_multi", arr(*[t.data_ptr() for t in partials]), arr(*[t.data_ptr() for t in outs]), n,
-              n_partials, cols, _stream())
+    pa, oa = arr(*[t.data_ptr() for t in partials]), arr(*[t.data_ptr() for t in outs])     # host arrays, alive over the call
+    _lib.call("shg_colsum_finish_multi", ctypes.addressof(pa), ctypes.addressof(oa), n, n_partials, cols, _stream())
 
 
 def colsum_finish(partial, out, accumulate):

@@ -38,3 +38,18 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(base, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_fastcall_trampoline_reaches_the_library_and_checks_arity():
+    """csrc_host/_fastcall.c: the low-overhead call path (no GPU needed: argument validation fails before any launch)."""
+    import pytest
+    from shg_vqa_amd import _lib
+    if _lib._fast is None:
+        pytest.skip("_fastcall extension not built")
+    with pytest.raises(_lib.ShgError, match="null pointer"):
+        _lib.call("shg_gemm", 0, 0, 0, 0, 1, 1, 8, 8, 8, 8, 8, 8, 1, 1, 0, 0)
+    with pytest.raises(_lib.ShgError, match="p_drop"):          # a float argument arrives in its register
+        _lib.call("shg_gemm_act", 16, 16, 16, 0, 1, 1, 8, 8, 8, 8, 8, 8, 1, 1, 0, 0, 1.5, 0, 0, 0)
+    ent = _lib._FAST["shg_gemm"]
+    with pytest.raises(TypeError):
+        _lib._fast.call(ent[0], ent[1], 1, 2, 3)
