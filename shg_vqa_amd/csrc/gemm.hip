@@ -893,11 +893,11 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
     return check_launch(what);
 }
 
-// the 8-phase kernel is used for bf16 problems with whole K-steps, >= 2 of them, at least `min_tiles`
+// the 8-phase kernel is used for bf16 problems with whole K-steps, >= 2 of them, at least `min_tiles` (about half the CUs)
 // 256 x 256 tiles and operands addressable with 32-bit byte offsets
 static bool use_gemm8(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t bytes_b) {
     static const int mode = []() { const char* e = getenv("SHG_GEMM8"); return e ? atoi(e) : 1; }();
-    static const int64_t min_tiles = []() { const char* e = getenv("SHG_GEMM8_MIN_TILES"); return e ? (int64_t)atoi(e) : (int64_t)96; }();
+    static const int64_t min_tiles = []() { const char* e = getenv("SHG_GEMM8_MIN_TILES"); return e ? (int64_t)atoi(e) : (int64_t)120; }();   // 96 tiles (4096 x 1536): the 128 x 128 kernel wins, 21 vs 31 us
     if (!mode || K % BK || K < 2 * BK) return false;
     if (bytes_a >= ((int64_t)1 << 32) || bytes_b >= ((int64_t)1 << 32)) return false;
     return ((M + 255) / 256) * ((N + 255) / 256) >= min_tiles;

@@ -402,7 +402,7 @@ def test_gemm_rejects_bad_arguments(K):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,T,H,W,Cin,Cout", [(2, 16, 7, 7, 128, 64), (1, 12, 7, 7, 64, 72), (3, 6, 5, 4, 64, 8),
-                                              (14, 16, 7, 7, 64, 768),      # bf16: forward on the 8-phase kernel (99 tiles)
+                                              (18, 16, 7, 7, 64, 768),      # bf16: forward on the 8-phase kernel (126 tiles)
                                               (4, 20, 7, 7, 256, 768)])     # bf16: weight gradient on the 8-phase kernel
 def test_conv3d_k533_fwd_wgrad_vs_torch(K, dtype, B, T, H, W, Cin, Cout):
     if Cout == 768 and dtype == torch.float32:
@@ -440,7 +440,7 @@ def test_conv3d_k533_fwd_wgrad_vs_torch(K, dtype, B, T, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype,shape", [(torch.float32, (2, 12, 7, 7, 64, 128)), (torch.bfloat16, (2, 12, 7, 7, 64, 128)),
-                                         (torch.bfloat16, (14, 12, 7, 7, 768, 64))])      # 8-phase kernel: 33 x 3 tiles
+                                         (torch.bfloat16, (18, 12, 7, 7, 768, 64))])      # 8-phase kernel: 42 x 3 tiles
 def test_conv3d_k533_dgrad_vs_torch(K, dtype, shape):
     gen = torch.Generator().manual_seed(21)
     B, T, H, W, Cin, Cout = shape
@@ -541,7 +541,7 @@ def test_colsum_finish_multi(K):
 
 # ------------------------------------------------------------------------------------------ 8-phase 256 x 256 kernel
 def test_gemm_8phase_kernel_shapes_and_epilogues(K):
-    """bf16, both operands contraction-contiguous, K a multiple of 64 and >= 96 tiles of 256 x 256 take the
+    """bf16, both operands contraction-contiguous, K a multiple of 64 and >= 120 tiles of 256 x 256 take the
     8-phase kernel (gemm.hip: gemm8_kernel): odd / even numbers of K-tiles, ragged M and N, every epilogue."""
     for (M, N, Kd) in [(4096, 3072, 128), (4104, 3080, 192), (3592, 3592, 832), (12576, 2304, 768), (6200, 4040, 64 * 7)]:
         _gemm_case(K, torch.bfloat16, True, True, M, N, Kd, False, torch.bfloat16, with_bias=True)
