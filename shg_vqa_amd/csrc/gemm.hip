@@ -667,6 +667,155 @@ __device__ __forceinline__ uint32_t tr_lane_base(const char* tile, int col0, int
     return (uint32_t)(uintptr_t)(lds_cptr)tile + Tile64<bf16_t>::elem_off_ks(8 * g + q, col0 + 4 * p);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128 x 128 x 64 tiles for SMALL problems (at most ~one workgroup per CU: the decoder / language / hyper-graph
+// projections, 72-320 tiles, 12-48 K-steps), built like the 8-phase kernel in miniature.
+// With one workgroup of four waves per CU the two-stage loop above runs ONE wave per SIMD: the issue of a K-step's
+// eight direct-to-LDS loads (~60 cycles each), its LDS reads and its 32 MFMAs are strictly serial
+// (measured 0.77 us per K-step against 0.21 us of MFMA work).  Here the tile is split over EIGHT waves (64 x 32
+// each: 16 MFMAs, 12 LDS reads, 4 loads per K-step) in two groups that run one barrier apart - the two waves of a
+// SIMD alternate between their load phase and their MFMA phase - over a four-buffer ring: a K-step stages K-tile
+// t+2 and retires K-tile t+1 with a counted vmcnt (one tile stays in flight across the raw barriers).
+//   step t of a group:  read tile t (12 ds_read) | stage tile t+2 -> buffer (t+2)%4 | vmcnt(4) | barrier |
+//                       lgkmcnt(0) | 16 MFMA | barrier
+//   RAW: a wave's share of tile t+1 is retired before the barrier that ends its load phase; both groups have passed
+//        such a barrier before either reads tile t+1.  WAR: buffer (t+2)%4 was last read two steps earlier.
+// bf16, both operands contraction-contiguous, K % 64 == 0, no split-K.  128 KiB of LDS.
+// ---------------------------------------------------------------------------------------------
+template <typename TC, typename SrcA, typename SrcB>
+__global__ __launch_bounds__(512) void gemm4_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
+                                                    int grid_m) {
+    static_assert(SrcA::KMAJOR && !SrcA::DYN && !SrcB::DYN, "A contraction-contiguous; B either layout (forward / input gradient)");
+    using T = bf16_t;
+    using TL = Tile64<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = 512, NCHK = 2, NS = 4;                  // 2 chunks per thread and operand per K-tile
+    constexpr bool BKM = SrcB::KMAJOR;
+    constexpr int STAGE_BYTES = 4 * TL::BYTES, B_OFF = 2 * TL::BYTES;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int grp = wave_u >> 2;                                  // waves w and w+4 share a SIMD: one from each group
+    const int wq = wave_u & 3, wr = wq >> 1;                      // group-local wave: rows wr*64.., columns (2*(wq&1)+grp)*32..
+    const int wc32 = 2 * (wq & 1) + grp;
+    const int64_t n_tiles = (int64_t)gridDim.x, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
+    const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
+    const int64_t tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
+    const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
+    const int64_t m0 = bm * 128, n0 = bn * 128;
+    sa.r0 = m0;
+    sb.r0 = n0;
+    uint32_t offa[NCHK], offb[NCHK];
+#pragma unroll
+    for (int i = 0; i < NCHK; ++i) {
+        offa[i] = sa.lane_off(tid, i, NTHR);
+        offb[i] = sb.lane_off(tid, i, NTHR);
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int64_t nk = K / BK;
+    auto stage = [&](int buf, int64_t kt) {                     // 4 wave instructions per thread
+        if (kt >= nk) return;
+        char* base = smem + buf * STAGE_BYTES + 64 * wave_u * 16;
+        const char* ka = sa.k_base(0, kt * BK);
+        const char* kb = sb.k_base(0, kt * BK);
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr)(ka + offa[i]), (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(kb + offb[i]), (lds_ptr)(base + B_OFF + NTHR * i * 16), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    stage(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                  // second group runs one barrier behind
+
+    Frag<T> fa[4][2], fb[2][2];
+    uint32_t trb[2] = {0, 0};                                     // contraction-strided B: per-lane LDS addresses in buffer 0
+    if constexpr (!BKM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) trb[j] = tr_lane_base(smem + B_OFF + (wc32 >> 1) * TL::BYTES, (wc32 & 1) * 32 + 16 * j, lane);
+    }
+    int cur = 0;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const char* tA = smem + cur * STAGE_BYTES + wr * TL::BYTES;
+        const char* tB = smem + cur * STAGE_BYTES + B_OFF + (wc32 >> 1) * TL::BYTES;
+        const int brow = (wc32 & 1) * 32 + li;
+        if constexpr (BKM) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb[j][ks] = lds_row_frag<T>(tB, brow + 16 * j, 32 * ks, g);
+        } else {
+            const uint32_t xo = (uint32_t)cur * STAGE_BYTES;
+            fb[0][0] = tr_frag<0, 0>(trb[0] + xo); fb[0][1] = tr_frag<0, 1>(trb[0] + xo);
+            fb[1][0] = tr_frag<0, 0>(trb[1] + xo); fb[1][1] = tr_frag<0, 1>(trb[1] + xo);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_row_frag<T>(tA, 16 * i + li, 32 * ks, g);
+        stage((cur + 2) & (NS - 1), kt + 2);
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile kt+1 has landed (this wave's share)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(acc[i][j], fb[j][ks], fa[i][ks]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        cur = (cur + 1) & (NS - 1);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();                  // re-align the groups
+    __syncthreads();
+    // epilogue: the two waves that share 64 columns (same wr, wc32 = 2c and 2c+1) fill one 64 x 64 staging piece;
+    // the even one writes it out
+    const int pair = wr * 2 + (wc32 >> 1);
+    float* stg = reinterpret_cast<float*>(smem) + pair * (64 * STG_LD);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<f32x4*>(stg + (16 * i + li) * STG_LD + 32 * (wc32 & 1) + 16 * j + 4 * g) = acc[i][j];
+    __syncthreads();
+    if ((wc32 & 1) == 0) RowWriter<TC>::run(stg, ep, m0 + wr * 64, n0 + 64 * (wc32 >> 1), M, N, lane);
+}
+
+template <typename TC, typename SrcA, typename SrcB>
+static int launch4(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what) {
+    const int64_t gm = (M + 127) / 128, gn = (N + 127) / 128;
+    const size_t lds = 4 * 4 * Tile64<bf16_t>::BYTES;
+    auto kern = gemm4_kernel<TC, SrcA, SrcB>;
+    static bool raised = false;
+    if (!raised) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn)), dim3(512), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn));
+    return check_launch(what);
+}
+
+// small bf16 NT problems (at most `max_tiles` 128 x 128 tiles: about one workgroup per CU) with whole K-steps
+static bool use_gemm4(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t bytes_b) {
+    static const int64_t max_tiles = []() { const char* e = getenv("SHG_GEMM4_MAX_TILES"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
+    if (K % BK || K < 2 * BK) return false;
+    if (bytes_a >= ((int64_t)1 << 32) || bytes_b >= ((int64_t)1 << 32)) return false;
+    return ((M + 127) / 128) * ((N + 127) / 128) <= max_tiles;
+}
+
 template <typename TC, typename SrcA, typename SrcB>
 __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
                                                     int grid_m) {
@@ -953,6 +1102,10 @@ static int gemm_plain(const T* A, const T* B, Epilogue<TC> ep, int64_t M, int64_
     if constexpr (std::is_same<T, bf16_t>::value && AK) {          // forward (NT) and input-gradient (NN) forms
         if (use_gemm8(M, N, K, M * lda * 2, (BK_ ? N : (int64_t)64) * ldb * 2))
             return launch8<TC, PlainSrc<T, true>, PlainSrc<T, BK_>>(sa, sb, ep, M, N, K, st, what);
+    }
+    if constexpr (std::is_same<T, bf16_t>::value && AK) {
+        if (use_gemm4(M, N, K, M * lda * 2, (BK_ ? N : (int64_t)64) * ldb * 2))
+            return launch4<TC, PlainSrc<T, true>, PlainSrc<T, BK_>>(sa, sb, ep, M, N, K, st, what);
     }
     if constexpr (std::is_same<T, bf16_t>::value) {
         if (use_large(1, M, N, K)) return launch_cfg<T, TC, PlainSrc<T, AK>, PlainSrc<T, BK_>, 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, what, split_ok);

@@ -713,3 +713,48 @@ def test_gemm_epilogue_dropout_uses_the_masks_of_the_standalone_kernels(K, dtype
         _assert_close(dx, dref, dtype)
         assert torch.equal(dx == 0, dref == 0)            # identical masks (and ReLU gates)
         assert torch.allclose(db.double().cpu(), dx.double().cpu().sum(0), rtol=1e-4, atol=2e-3 * math.sqrt(M))
+
+
+def test_gemm_small_problem_kernel(K):
+    """bf16 NT problems of at most 256 tiles of 128 x 128 with K % 64 == 0 take the 8-wave small-problem kernel
+    (gemm.hip: gemm4_kernel): every K-tile count from 2 up (prologue / tail paths), ragged M and N, every epilogue,
+    and an integer-exact race screen (a K-tile of direct-to-LDS prefetch stays in flight across each barrier)."""
+    for nk in (2, 3, 4, 5, 12, 33):
+        _gemm_case(K, torch.bfloat16, True, True, 1000, 776, 64 * nk, False, torch.bfloat16, with_bias=True)
+    for (M, N, Kd) in [(4096, 768, 768), (1536, 2048, 768), (1280, 3072, 768), (4096, 1536, 768), (72, 64, 128)]:
+        _gemm_case(K, torch.bfloat16, True, True, M, N, Kd, False, torch.bfloat16, with_bias=True)
+        _gemm_case(K, torch.bfloat16, True, True, M, N, Kd, False, torch.float32, with_bias=False)
+    _gemm_case(K, torch.bfloat16, True, True, 1280, 768, 512, True, torch.float32, with_bias=False)
+    _gemm_case(K, torch.bfloat16, True, True, 1280, 768, 512, True, torch.bfloat16, with_bias=False)
+    # input-gradient form: B contraction-strided (transposing LDS reads)
+    for (M, N, Kd) in [(4096, 768, 768), (1536, 768, 2048), (1000, 776, 192), (1280, 768, 3072)]:
+        _gemm_case(K, torch.bfloat16, True, False, M, N, Kd, False, torch.bfloat16, with_bias=False)
+    _gemm_case(K, torch.bfloat16, True, False, 1280, 768, 2304, True, torch.bfloat16, with_bias=False)
+    M, N, Kd = 2048, 1536, 4096
+    gen = torch.Generator().manual_seed(19)
+    a = torch.randint(-3, 4, (M, Kd), generator=gen).float()
+    b = torch.randint(-2, 3, (N, Kd), generator=gen).float()
+    ref = (a.to(DEV) @ b.to(DEV).t()).cpu()
+    aa, bb = a.bfloat16().to(DEV), b.bfloat16().to(DEV)
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    for it in range(5):
+        out = torch.empty(M, N, device=DEV)
+        with torch.cuda.stream(side):
+            big.copy_(big.flip(0)) if it % 2 else big.zero_()
+        if it < 3:
+            K.gemm(aa, bb, out, None, True, True)
+        else:
+            K.gemm(aa, bb.t().contiguous(), out, None, True, False)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref), it
+    # layout check with asymmetric integers (a swapped fragment or stage shows up as a wrong entry)
+    M, N, Kd = 384, 256, 192
+    a = (torch.arange(M * Kd).view(M, Kd) % 7 - 3).float()
+    b = (torch.arange(N * Kd).view(N, Kd) % 5 - 2).float()
+    b[3, 5] = 9
+    out = torch.empty(M, N, device=DEV)
+    K.gemm(a.bfloat16().to(DEV), b.bfloat16().to(DEV), out, None, True, True)
+    assert torch.equal(out.cpu(), a @ b.t())
+    K.gemm(a.bfloat16().to(DEV), b.t().contiguous().bfloat16().to(DEV), out, None, True, False)
+    assert torch.equal(out.cpu(), a @ b.t())
