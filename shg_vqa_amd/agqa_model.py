@@ -58,6 +58,16 @@ class HGDecoder(nn.Module):
         def decode(emb, dec, seg, per):
             qpos = emb(seg)
             mask = rel_target_mask_device(self.num_situations, per, dev)
+            E = engine()
+            if (E.graph_decoders and E.training and torch.is_grad_enabled() and memory.requires_grad
+                    and not torch.cuda.is_current_stream_capturing()):
+                # the decoder's ~80 forward / ~200 backward launches as two hipGraph replays (graphed.py)
+                key = (id(dec), tuple(memory.shape), tuple(qpos.shape), memory.dtype)
+                segs = self.__dict__.setdefault("_graphed", {})
+                if key not in segs:
+                    from .graphed import GraphedSegment
+                    segs[key] = GraphedSegment(lambda m, q: dec.forward_bf(torch.zeros_like(q), m, q, mask), [memory, qpos])
+                return segs[key](memory, qpos)
             return dec.forward_bf(torch.zeros_like(qpos), memory, qpos, mask)
 
         # the two decoders only share `memory`: the action decoder runs on a side stream beside the

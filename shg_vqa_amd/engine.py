@@ -65,6 +65,8 @@ class Engine:
         self.defer_x_layers = False
         self.deferred_branch = None
         self.grad_dirty = False           # gradients written since the arena was last zeroed
+        self.capture_segment = None       # graphed.GraphedSegment whose backward is being captured
+        self.graph_decoders = os.environ.get("SHG_GRAPH_DECODERS", "0") != "0"   # hipGraph replay of the decoders (graphed.py)
         self.params_ready_event = None
         # set per call by AGQA.train_step(overlap_update=True): the caller then waits (wait_params_ready / a device
         # synchronisation / the next train_step) before it reads parameters on another stream
@@ -200,11 +202,16 @@ class Engine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def mark_grads_dirty(self):
-        self.grad_dirty = True
+    def begin_capture_pass(self, segment):
+        """graphed.GraphedSegment: while a segment's backward is captured, weight gradients and gradient-ready
+        notifications are recorded on it instead of being issued."""
+        self.capture_segment = segment
 
     def grad_written(self, p):
         self.grad_dirty = True
+        if self.capture_segment is not None:
+            self.capture_segment.record_written(p)
+            return
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(p._shg_off, p._shg_numel)
 

@@ -162,6 +162,9 @@ def _wgrad(dy2, x2, weight, bias):
     E = engine()
     if weight._shg_grad is None:
         return
+    if E.capture_segment is not None:          # backward of a graphed segment being captured: issued after each replay
+        E.capture_segment.record_wgrad(dy2, x2, weight, bias)
+        return
     if E.wgrad_batch > 1 and E.wgrad_stream() is not None:
         E.deferred_wgrads.append((torch.cuda.current_stream(), dy2, x2, weight, bias))
         if len(E.deferred_wgrads) >= E.wgrad_batch:

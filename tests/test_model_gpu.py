@@ -383,3 +383,24 @@ def test_overlapped_optimizer_update_gives_the_same_parameters():
     assert (g0 == 0).all() and (g1 == 0).all()          # the optimiser pass leaves the gradient arena zeroed
     # fp32 atomics in the split-K weight gradients / column sums make two runs differ in the last bits
     assert torch.allclose(p0, p1, rtol=0, atol=2e-6), (p0 - p1).abs().max()
+
+
+def test_graphed_decoder_segments_match_eager():
+    """Engine.graph_decoders (graphed.py): each decoder's forward / backward replayed from two hipGraphs, weight
+    gradients issued eagerly after the backward replay.  Two optimiser steps must land on the eager parameters."""
+    from oracle import shg_ref
+    from shg_vqa_amd.engine import engine
+    res = []
+    for graphed in (False, True):
+        tr = _build(torch.bfloat16)
+        engine().graph_decoders = graphed
+        cfg = shg_ref.Cfg()
+        batches = [_device_batch(shg_ref.synthetic_batch(2, cfg, seed=70 + i)) for i in range(3)]
+        for m in tr.model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        outs = [float(tr.train_step(b)["total"]) for b in batches]
+        torch.cuda.synchronize()
+        res.append((engine().param_arena.clone(), outs))
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(res[0][1], res[1][1])), (res[0][1], res[1][1])
+    assert torch.allclose(res[0][0], res[1][0], rtol=0, atol=2e-6), (res[0][0] - res[1][0]).abs().max()
