@@ -245,19 +245,26 @@ class AGQA:
                 E.conv1_cache = self._conv1_bufs
             return self._step_body(self._static)
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):                      # warm-up: caches (masks, gather tables), DDP write counts
-                if w1 is not None:
-                    _ops.conv1_forward(self._static["feat"], w1, b1, self._conv1_bufs)
-                body()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._graph_out = body()
-        E.conv1_cache = None
+        # The captured step keeps the weight-gradient stream but not the model's side-stream branches: ending a
+        # capture that holds their fork/re-enter/late-join pattern crashes inside the HIP runtime (ROCm 7.0), and
+        # the replayed graph serialises its branches anyway ("hipGraph mode").
+        branches, E.overlap_branches = E.overlap_branches, False
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                  # warm-up: caches (masks, gather tables), DDP write counts
+                    if w1 is not None:
+                        _ops.conv1_forward(self._static["feat"], w1, b1, self._conv1_bufs)
+                    body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_out = body()
+        finally:
+            E.overlap_branches = branches
+            E.conv1_cache = None
         return self
 
     def train_step_graphed(self, b):

@@ -175,7 +175,8 @@ class Engine:
         return self._aux_streams[i]
 
     def side_streams(self):
-        return [s for s in (self._wgrad_stream,) if s is not None] + list(self._aux_streams.values())
+        aux = list(self._aux_streams.values()) if self.overlap_branches else []    # (idle while branches run inline)
+        return [s for s in (self._wgrad_stream,) if s is not None] + aux
 
     def join_side_streams(self):
         """Makes the current stream wait for all weight-gradient work issued so far."""

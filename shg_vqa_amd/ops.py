@@ -88,7 +88,9 @@ class Branch:
 
     def __enter__(self):
         if self.side is not None:
-            if self.wait:
+            # (under hipGraph capture every entry forks from the capturing stream: a launch on a stream that has
+            # not joined the capture would not be part of the graph)
+            if self.wait or torch.cuda.is_current_stream_capturing():
                 self.side.wait_stream(self.main)
             for t in self.inputs:
                 if t is not None:

@@ -422,3 +422,33 @@ def test_graphed_decoder_segments_match_eager():
         # (autograd adds the decoders' bf16 memory gradients in a different order: bf16-level agreement)
         assert torch.allclose(g0, g1, rtol=2e-2, atol=2e-4 * g0.abs().max().item()), (g0 - g1).abs().max()
         assert abs(g0.double().norm().item() - g1.double().norm().item()) <= 1e-3 * g0.double().norm().item()
+
+
+def test_whole_step_hipgraph_replay_matches_eager_steps():
+    """AGQA.capture / train_step_graphed (bench.py --exec graph): the optimiser step captured into one hipGraph (model
+    branches inline, weight gradients on their side stream) gives the losses of eager multi-stream steps."""
+    from oracle import shg_ref
+    from shg_vqa_amd.transformer import MultiheadAttention
+    cfg = shg_ref.Cfg()
+    losses = []
+    for graphed in (False, True):
+        tr = _build(torch.bfloat16)
+        batches = [_device_batch(shg_ref.synthetic_batch(2, cfg, seed=90 + i)) for i in range(3)]
+        for m in tr.model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if isinstance(m, MultiheadAttention):
+                m.dropout = 0.0
+        tr.train_step(batches[0])              # (creates the side streams the capture then has to leave alone)
+        if graphed:
+            tr.capture(batches[0])             # two warm-up steps on the example batch; the capture pass itself runs nothing
+            out = [float(tr.train_step_graphed(b)["total"]) for b in batches]
+            out.append(float(tr.train_step(batches[0])["total"]))       # and eager steps still work afterwards
+        else:
+            for _ in range(2):
+                tr.train_step(batches[0])
+            out = [float(tr.train_step(b)["total"]) for b in batches + batches[:1]]
+        torch.cuda.synchronize()
+        losses.append(out)
+    for a, b in zip(*losses):
+        assert abs(a - b) <= 2e-3 * abs(a), losses
