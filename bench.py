@@ -27,6 +27,8 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 TRAIN_GFLOP_PER_QA = 428.21        # fwd + required bwd GEMM-like work per QA pair (HGQA)
+FWD_GFLOP_PER_QA = 178.79          # same table: forward only
+STACK_FWD_GFLOP_PER_QA = 45.50     # same table: the attention stack alone (5 l-layers S=40, 5 r-layers S=393, 2 x-layers 40<->393)
 
 
 def synthetic_device_batches(n_batches, bsz, seed, device):
@@ -66,6 +68,76 @@ def cpu_baseline(bsz=4, timed=4):
                       "(%.1f s/step)" % (bsz, timed, per)}
 
 
+def forward_only(trainer, batches, iters=10):
+    """SURVEY 8(d) "forward-only QA-pairs/s": the predict() pass (eval mode, no autograd graph, same kernels)."""
+    from shg_vqa_amd.engine import engine
+    E = engine()
+    trainer.model.eval()
+    E.wait_params_ready()
+    times = []
+    with torch.no_grad():
+        for i in range(2 + iters):
+            if i == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            E.begin_step()
+            trainer.forward_losses(batches[i % len(batches)])
+        torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / iters
+    trainer.model.train()
+    bsz = batches[0]["input_ids"].shape[0]
+    qa = bsz / per
+    return {"value": round(qa, 1), "unit": "QA-pairs/s", "ms_per_batch": round(1e3 * per, 3),
+            "mfma_frac": round(qa * FWD_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)}
+
+
+def attention_stack(trainer, bsz, iters=8):
+    """SURVEY 8(d) sub-roofline of the attention stack alone: the encoder's 5 language layers (S = 40), 5 relation layers
+    (S = 393) and 2 cross layers (40 <-> 393), forward + backward (input, weight and bias gradients, dropout on) on
+    hidden states of the training shape, without the convolutions / decoders / losses around them."""
+    from shg_vqa_amd import ops
+    from shg_vqa_amd.engine import engine
+    from shg_vqa_amd.modeling import additive_mask
+    E = engine()
+    enc = trainer.model.lxrt_encoder.model.bert.encoder
+    dev, cdt = E.device, E.compute_dtype
+    gen = torch.Generator(device="cpu").manual_seed(4321)
+    lang0 = torch.randn(bsz, 40, 768, generator=gen).to(dev, cdt)
+    visn0 = torch.randn(bsz, 393, 768, generator=gen).to(dev, cdt)
+    lens = torch.randint(8, 31, (bsz,), generator=gen)
+    mask01 = (torch.arange(40)[None, :] < lens[:, None]).long().to(dev)
+    lmask = additive_mask(mask01, mask01)
+    trainer.model.train()
+    E.training = True
+    ms = []
+    for i in range(2 + iters):
+        lang, visn = lang0.clone().requires_grad_(True), visn0.clone().requires_grad_(True)
+        E.begin_step()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        l, v = lang, visn
+        for layer in enc.layer:
+            l, _ = layer(l, lmask)
+        for layer in enc.r_layers:
+            v, _ = layer(v, None)
+        for layer in enc.x_layers:
+            l, v, _ = layer(l, lmask, v, None)
+        torch.autograd.backward([l, v], [torch.ones_like(l), torch.ones_like(v)])
+        ops.flush_wgrads()
+        E.join_side_streams()
+        s1.record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            ms.append(s0.elapsed_time(s1))
+    E.grad_dirty = True
+    E.zero_grad()
+    per = sum(ms) / len(ms)
+    tflops = 3.0 * STACK_FWD_GFLOP_PER_QA * 1e9 * bsz / (per * 1e-3) / 1e12
+    return {"ms_fwd_bwd": round(per, 3), "achieved": round(tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / PEAK_BF16_TFLOPS, 4),
+            "flop": "3 x %.2f GFLOP per QA pair (forward, SURVEY 8(d)) x %d" % (STACK_FWD_GFLOP_PER_QA, bsz)}
+
+
 _T0 = time.perf_counter()
 
 
@@ -82,6 +154,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and attention-stack measurements (N=1)")
     ap.add_argument("--overlap-update", action="store_true", help="overlap BertAdam's sweep with the next step's conv1")
     ap.add_argument("--force-ddp", action="store_true", help="use the gradient reducer / RCCL path even with one rank (testing)")
     ap.add_argument("--exec", dest="exec_mode", default="auto", choices=["auto", "graph", "eager"],
@@ -189,6 +262,10 @@ def main():
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(k_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs)},
         }
+        if world == 1 and mode == "eager" and a.dtype == "bf16" and not a.no_extras:
+            log("forward-only pass and attention-stack sub-roofline ...")
+            line["forward_only"] = forward_only(trainer, batches)
+            line["attention_stack"] = attention_stack(trainer, B)
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle) ...")
             line["cpu_baseline"] = cpu_baseline()
