@@ -5,8 +5,9 @@ import torch
 from shg_vqa_amd import kernels as K
 from gemm_shapes import bench  # noqa
 
-for (M, N) in ((1280, 768), (4096, 768), (12576, 768)):
-    for Kd in (64, 128, 256, 512, 768, 1536, 3072):
+SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1280, 768), (4096, 768), (12576, 768)]
+for (M, N) in SHAPES:
+    for Kd in (64, 128, 256, 512, 768, 1536, 3072, 6144):
         x = torch.randn(M, Kd, device="cuda").bfloat16()
         w = torch.randn(N, Kd, device="cuda").bfloat16()
         y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
