@@ -298,8 +298,10 @@ template <bool FAST = false> __device__ __forceinline__ float apply_act(float x,
 // 128/256-byte row segments.
 template <typename TC> struct RowWriter;
 template <> struct RowWriter<bf16_t> {
+    // csum_carry (8 floats per lane, zero-initialised by the caller): the column sums of this piece are added to it instead
+    // of going to memory; the caller flushes them once with flush_csum (fewer atomics on the shared bias-gradient vector)
     __device__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
-                               int64_t N, int lane, int gap = 0) {
+                               int64_t N, int lane, int gap = 0, float* csum_carry = nullptr) {
         float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const uint64_t dseed = ep.drop_thr ? dropout_seed(ep.seed_state, ep.stream_id) : 0;
         // a lane keeps its 8 columns through all 8 row passes: their bias is loaded once, ahead of the loop (per-element
@@ -372,24 +374,37 @@ template <> struct RowWriter<bf16_t> {
                 }
             }
         }
-        if (ep.csum) {                                   // lanes l, l+8, .. l+56 hold the same 8 columns
+        if (ep.csum) {
+            if (csum_carry) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float v = csum8[r];
-                v += __shfl_xor(v, 8);
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                csum8[r] = v;
+                for (int r = 0; r < 8; ++r) csum_carry[r] += csum8[r];
+            } else {
+                flush_csum(csum8, ep, nbase, N, lane, gap);
             }
-            if (lane < 8)
-                for (int r = 0; r < 8; ++r)
-                    if (n + r < N) atomicAdd(ep.csum + n + r, csum8[r]);
         }
+    }
+    // lanes l, l+8, .. l+56 hold partial sums of the same 8 columns: after the butterfly every lane has the totals of its
+    // column group, and lane L adds element L >> 3 of it - ONE atomic instruction over 64 consecutive floats per wave (eight
+    // instructions of 8 lanes with a 32-byte stride cost 25 us on a 150-tile launch: the L2 serialises atomics per line)
+    __device__ static void flush_csum(float* csum8, const Epilogue<bf16_t>& ep, int64_t nbase, int64_t N, int lane, int gap = 0) {
+        const int col = (lane & 7) * 8, sel = lane >> 3;
+        const int64_t n = nbase + col + (col >= 32 ? gap : 0) + sel;
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float v = csum8[r];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            mine = sel == r ? v : mine;
+        }
+        if (n < N) atomicAdd(ep.csum + n, mine);
     }
 };
 template <> struct RowWriter<float> {
+    __device__ static void flush_csum(float*, const Epilogue<float>&, int64_t, int64_t, int, int = 0) {}
     __device__ static void run(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
-                               int64_t N, int lane, int gap = 0) {
+                               int64_t N, int lane, int gap = 0, float* /*csum_carry: fp32 outputs flush per piece*/ = nullptr) {
         if (ep.atomic) {                               // one 256-byte row segment per wave instruction
             const int64_t n = nbase + lane + (lane >= 32 ? gap : 0);
             for (int row = 0; row < 64; ++row) {
@@ -1030,6 +1045,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
     float* stg0 = reinterpret_cast<float*>(smem) + (wave & ~1) * (64 * STG_LD);     // the pair's left block (columns 64 q ..)
     float* stg1 = stg0 + 64 * STG_LD;                                               // its right block (columns 128 + 64 q ..)
     const int half = wc & 1;
+    float csum_carry[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bias-gradient sums of both A halves (same columns)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         if (a) __syncthreads();
@@ -1041,8 +1057,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
                 for (int j = 0; j < 2; ++j)
                     *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li) * STG_LD + 32 * half + 16 * j + 4 * g) = acc[a][b][i][j];
         __syncthreads();
-        RowWriter<TC>::run(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane);
+        RowWriter<TC>::run(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane, 0,
+                           csum_carry);
     }
+    if (ep.csum) RowWriter<TC>::flush_csum(csum_carry, ep, n0 + 128 * half + 64 * (wc >> 1), N, lane);
 }
 
 template <typename TC, typename SrcA, typename SrcB>
