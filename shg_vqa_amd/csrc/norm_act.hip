@@ -9,7 +9,7 @@
 namespace shg {
 
 constexpr int LN_MAX_CHUNKS = 8;        // 16-byte chunks per lane held in registers
-constexpr int ROWS_PER_PARTIAL = 8;   // rows folded into one partial row of the column sums
+constexpr int ROWS_PER_PARTIAL = 16;  // rows folded into one partial row of the column sums
 constexpr int MAX_PARTIALS = 4096;
 
 __host__ inline int colsum_partials(int64_t rows) {
