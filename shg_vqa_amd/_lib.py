@@ -29,6 +29,7 @@ _SIGNATURES = {
     "shg_bias_act_drop_res_ln_fwd": ([P, P, P, P, P, P, P, P, P, I, L, I, I, F, F, P, U, P], c_int),
     "shg_bias_act_drop_res_ln_bwd": ([P, P, P, P, P, P, P, P, P, P, P, P, I, I, L, I, I, F, P, U, P], c_int),
     "shg_colsum_partial": ([P, I, L, I, L, P, I, P], c_int),
+    "shg_colsum_accumulate": ([P, I, L, I, L, P, P], c_int),
     "shg_colsum_finish": ([P, I, I, P, I, P], c_int),
     "shg_colsum_finish_multi": ([P, P, I, I, I, P], c_int),
     "shg_colsum_partials": ([L], c_int),

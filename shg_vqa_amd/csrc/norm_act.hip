@@ -301,6 +301,46 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     partial[(int64_t)blockIdx.y * cols + c] = acc;
 }
 
+// column sums straight into the gradient vector: one wave per row, 16-byte loads, four rows in flight per wave; the four
+// waves' partial sums meet in LDS and leave as 64-lane atomics (consecutive lanes = consecutive columns)
+constexpr int COLSUM_ROWS_PER_BLOCK = 64;
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void colsum_atomic_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                            int cols, int64_t ld) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = cols / V;
+    const int64_t r_begin = (int64_t)blockIdx.x * COLSUM_ROWS_PER_BLOCK;
+    const int64_t r_end = min(rows, r_begin + COLSUM_ROWS_PER_BLOCK);
+    float acc[NCH][V];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[i][j] = 0.f;
+#pragma unroll 4
+    for (int64_t row = r_begin + wave; row < r_end; row += 4) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                const Vec16<T> v = load16(x + row * ld + ch * V);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[i][j] += v.get(j);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = lane + i * 64;
+        if (ch < nchunk)
+#pragma unroll
+            for (int j = 0; j < V; ++j) red[wave * cols + ch * V + j] = acc[i][j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) atomicAdd(out + c, red[c] + red[cols + c] + red[2 * cols + c] + red[3 * cols + c]);
+}
+
 // second stage of the column reductions: block = 64 columns x 16 partial-row groups; the partial rows
 // are cut into gridDim.y slices whose sums are combined with fp32 atomics (<= 8 adders per address)
 __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ partial, int n_partials, int cols,
@@ -417,6 +457,31 @@ extern "C" int shg_colsum_partial(const void* x, int dtype, int64_t rows, int co
     else if (dtype == SHG_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, partial, rows, cols, ld);
     else return fail_arg("colsum_partial: bad dtype");
     return check_launch("colsum_partial");
+}
+
+template <typename T>
+static int colsum_accumulate_t(const T* x, int64_t rows, int cols, int64_t ld, float* out, hipStream_t st) {
+    constexpr int V = Vec16<T>::N;
+    if (cols % V || ld % V || (reinterpret_cast<uintptr_t>(x) & 15)) return fail_arg("colsum_accumulate: cols / ld / alignment must allow 16-byte loads");
+    const int nch = (cols / V + 63) / 64;
+    const dim3 grid((unsigned)((rows + COLSUM_ROWS_PER_BLOCK - 1) / COLSUM_ROWS_PER_BLOCK)), block(256);
+    const size_t lds = (size_t)4 * cols * sizeof(float);
+    switch (nch) {
+        case 1: hipLaunchKernelGGL((colsum_atomic_kernel<T, 1>), grid, block, lds, st, x, out, rows, cols, ld); break;
+        case 2: hipLaunchKernelGGL((colsum_atomic_kernel<T, 2>), grid, block, lds, st, x, out, rows, cols, ld); break;
+        case 3: case 4: hipLaunchKernelGGL((colsum_atomic_kernel<T, 4>), grid, block, lds, st, x, out, rows, cols, ld); break;
+        case 5: case 6: case 7: case 8: hipLaunchKernelGGL((colsum_atomic_kernel<T, 8>), grid, block, lds, st, x, out, rows, cols, ld); break;
+        default: return fail_arg("colsum_accumulate: cols too large");
+    }
+    return check_launch("colsum_accumulate");
+}
+
+extern "C" int shg_colsum_accumulate(const void* x, int dtype, int64_t rows, int cols, int64_t ld, float* out, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || cols > 4096 || ld < cols) return fail_arg("colsum_accumulate: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) return colsum_accumulate_t<float>((const float*)x, rows, cols, ld, out, st);
+    if (dtype == SHG_BF16) return colsum_accumulate_t<bf16_t>((const bf16_t*)x, rows, cols, ld, out, st);
+    return fail_arg("colsum_accumulate: bad dtype");
 }
 
 extern "C" int shg_colsum_finish(const float* partial, int n_partials, int cols, float* out, int accumulate, void* stream) {

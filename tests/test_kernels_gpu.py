@@ -528,6 +528,25 @@ def test_gemm_accumulates_into_bf16_output(K):
         assert torch.allclose(c.float().cpu(), ref, rtol=1e-2, atol=1e-2), (c.float().cpu() - ref).abs().max()
 
 
+def test_colsum_single_launch_and_two_stage_paths(K):
+    """K.colsum: bias gradient of an nn.Linear.  Accumulating sums of 16-byte-loadable matrices take the single-launch atomic
+    kernel (shg_colsum_accumulate), everything else the two-stage partial / finish kernels; both against float64."""
+    gen = torch.Generator().manual_seed(5)
+    cases = [(12576, 768, torch.bfloat16, None), (4096, 2304, torch.bfloat16, 768), (1280, 3072, torch.bfloat16, None),
+             (37, 1536, torch.bfloat16, None), (300, 456, torch.float32, None), (130, 171, torch.float32, None),
+             (64, 4096, torch.bfloat16, None)]
+    for rows, cols, dt, sl in cases:
+        x = torch.randn(rows, cols, generator=gen).to(dt).to(DEV)
+        view = x[:, sl:2 * sl] if sl else x                     # a column slice: rows `cols` elements apart
+        ref = view.double().sum(0).cpu()
+        for accumulate in (True, False):
+            out0 = torch.randn(view.shape[1], generator=gen).to(DEV)
+            out = out0.clone()
+            K.colsum(view, out, accumulate)
+            want = ref + (out0.double().cpu() if accumulate else 0.0)
+            assert torch.allclose(out.double().cpu(), want, rtol=1e-5, atol=2e-3 * math.sqrt(rows)), (rows, cols, dt, accumulate)
+
+
 def test_colsum_finish_multi(K):
     gen = torch.Generator().manual_seed(3)
     for (npart, cols, n) in [(1572, 768, 3), (16, 1536, 2), (300, 72, 4), (1, 768, 1)]:
