@@ -142,7 +142,7 @@ int shg_colsum_finish_multi(const float* const* partials, float* const* outs, in
 int shg_colsum_partials(int64_t rows);
 /* out[c] += sum_r x[r, c] in ONE launch (the bias gradient of an nn.Linear, modeling_capsbert.py:373-375, next to its
  * weight-gradient GEMM): 16-byte loads, 64 rows per workgroup, one 64-lane fp32 atomic per wave and 64 columns.
- * bf16 / fp32, cols % 8 (bf16) or % 4 (fp32) == 0, ld likewise, x 16-byte aligned; cols <= 4096.  The summation order
+ * bf16 / fp32, cols % 8 (bf16) or % 4 (fp32) == 0, ld likewise, x 16-byte aligned; cols <= 4096 (bf16) / 2048 (fp32).  The summation order
  * across workgroups is not fixed (fp32 atomics), like the bias sums of shg_gemm_dact. */
 int shg_colsum_accumulate(const void* x, int dtype, int64_t rows, int cols, int64_t ld, float* out, void* stream);
 

@@ -141,7 +141,7 @@ def colsum(x2d, out, accumulate):
     _need(x2d.dim() == 2 and x2d.stride(1) == 1, "x must be 2-D with contiguous inner dim")
     rows, cols = x2d.shape
     vec = 16 // x2d.element_size()
-    if accumulate and cols % vec == 0 and x2d.stride(0) % vec == 0 and x2d.data_ptr() % 16 == 0 and cols <= 4096:
+    if accumulate and cols % vec == 0 and x2d.stride(0) % vec == 0 and x2d.data_ptr() % 16 == 0 and cols <= 512 * vec:
         _need(out.numel() == cols and out.dtype == torch.float32 and out.is_contiguous(), "out must be fp32 [cols]")
         _lib.call("shg_colsum_accumulate", x2d.data_ptr(), _dt(x2d), rows, cols, x2d.stride(0), out.data_ptr(), _stream())
         return

@@ -534,7 +534,7 @@ def test_colsum_single_launch_and_two_stage_paths(K):
     gen = torch.Generator().manual_seed(5)
     cases = [(12576, 768, torch.bfloat16, None), (4096, 2304, torch.bfloat16, 768), (1280, 3072, torch.bfloat16, None),
              (37, 1536, torch.bfloat16, None), (300, 456, torch.float32, None), (130, 171, torch.float32, None),
-             (64, 4096, torch.bfloat16, None)]
+             (64, 4096, torch.bfloat16, None), (200, 2304, torch.float32, None), (96, 2048, torch.float32, None)]
     for rows, cols, dt, sl in cases:
         x = torch.randn(rows, cols, generator=gen).to(dt).to(DEV)
         view = x[:, sl:2 * sl] if sl else x                     # a column slice: rows `cols` elements apart
