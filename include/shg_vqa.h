@@ -44,6 +44,9 @@ extern "C" {
 
 int shg_version(void);
 const char* shg_last_error_string(void);
+/* Diagnostics: number of convolution launches so far that used the stream-K work split of the 256 x 256 kernel (gemm.hip:
+ * every CU gets the same number of K-tiles).  Tests use it to prove the path was exercised. */
+int64_t shg_gemm_streamk_launches(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matcher, per-frame branch.

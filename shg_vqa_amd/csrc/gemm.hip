@@ -20,6 +20,9 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 
@@ -848,9 +851,51 @@ static bool use_gemm4(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t 
     return ((M + 127) / 128) * ((N + 127) / 128) <= max_tiles;
 }
 
-template <typename TC, typename SrcA, typename SrcB>
+// Stream-K work split of the 8-phase kernel (template parameter SK; the convolutions, whose 147 / 222 / 1 080 tiles fill 57 / 87 /
+// 84 % of the CU-rounds they occupy).  The grid is 8 x 32 workgroups, blockIdx % 8 = the XCD the dispatcher puts a workgroup on.
+// Each XCD owns a contiguous run of output tiles (the same run as in the one-tile-per-workgroup launch: neighbours share operand
+// panels in that XCD's L2) and its 32 workgroups cut the run's K-tiles ("iterations") into 32 equal contiguous ranges.  A range
+// covers the tail of one tile, whole tiles, and the head of the next.  The workgroup whose range holds a tile's LAST iteration
+// owns the tile: it adds the partial sums of the others and runs the epilogue.  A workgroup computes its unowned head segment
+// FIRST and publishes it (fp32, one 256 KiB slot per workgroup, then a flag); owners therefore only wait for workgroups with a
+// lower blockIdx on the same XCD, which were dispatched earlier and never wait before publishing: no deadlock whatever else
+// shares the chip.  The owner clears the flag, so a launch leaves the flags zero.
+struct StreamK {
+    float* ws;
+    int* flags;
+    int n_tiles;
+};
+constexpr int STREAMK_WGS = 256;
+constexpr size_t STREAMK_SLOT = (size_t)256 * 256;          // floats per partial tile
+
+struct StreamKSeg {
+    int tile, kb, nk, owner, c_first;                        // nk == 0: no such segment
+};
+// segment `seg` of this workgroup (32-bit scalar arithmetic, recomputed where needed instead of kept in registers: the kernel
+// has no register to spare across its main loop)
+__device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_all, int seg) {
+    StreamKSeg d{0, 0, 0, 0, 0};
+    const int n_tiles = sk.n_tiles, xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int wgs = gridDim.x >> 3;
+    const int tile0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int iters = (xq + (xcd < xr ? 1 : 0)) * nk_all, per = (iters + wgs - 1) / wgs;
+    const int lo = min(iters, j * per), hi = min(iters, lo + per);
+    if (hi <= lo) return d;
+    const int lt_first = lo / nk_all, lt_last = (hi - 1) / nk_all;
+    const int head_first = hi % nk_all != 0;                  // the last tile of the range is not finished here: do it first
+    if (seg > lt_last - lt_first) return d;
+    const int lt = head_first ? (seg == 0 ? lt_last : lt_first + seg - 1) : lt_first + seg;
+    d.kb = max(lo, lt * nk_all) - lt * nk_all;
+    d.nk = min(hi, (lt + 1) * nk_all) - lt * nk_all - d.kb;
+    d.owner = d.kb + d.nk == nk_all;
+    d.c_first = (lt * nk_all) / per;
+    d.tile = tile0 + lt;
+    return d;
+}
+
+template <typename TC, typename SrcA, typename SrcB, bool SK = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
-                                                    int grid_m) {
+                                                    int grid_m, StreamK sk) {
     static_assert(!SrcA::DYN, "only the B operand may gather per K-tile");
     using T = bf16_t;
     using TL = Tile64<T>;
@@ -860,21 +905,33 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wr = wave_u >> 2, wc = wave_u & 3;
+    const int64_t nk_all = K / BK;
     // grid_m < 0: walk M fastest instead (few row tiles, many column tiles - the weight-gradient shapes - so
     // that the tiles sharing a B column-panel sit next to each other)
-    const int64_t n_tiles = (int64_t)gridDim.x, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
-    const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
-    const int64_t tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
+    const int64_t n_tiles = SK ? (int64_t)sk.n_tiles : (int64_t)gridDim.x, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
+
+#pragma nounroll
+    for (int seg = 0; seg < (SK ? 64 : 1); ++seg) {
+    int64_t tile, kb, nk;
+    if constexpr (SK) {
+        int s_ = seg;
+        asm volatile("" : "+s"(s_));
+        const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
+        if (d.nk == 0) break;
+        tile = d.tile; kb = d.kb; nk = d.nk;
+    } else {
+        const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
+        tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
+        // K range of this workgroup (gridDim.y > 1: split-K, partial sums added with atomics by the epilogue)
+        const int64_t per_split = (nk_all + gridDim.y - 1) / gridDim.y;
+        kb = (int64_t)blockIdx.y * per_split;
+        nk = min(nk_all, kb + per_split) - kb;               // K-tiles of this workgroup, numbered 0 .. nk-1 below
+        if (nk <= 0) return;
+    }
     const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
     const int64_t m0 = bm * 256, n0 = bn * 256;
     sa.r0 = m0;
     sb.r0 = n0;
-    // K range of this workgroup (gridDim.y > 1: split-K, partial sums added with atomics by the epilogue)
-    const int64_t nk_all = K / BK;
-    const int64_t per_split = (nk_all + gridDim.y - 1) / gridDim.y;
-    const int64_t kb = (int64_t)blockIdx.y * per_split;
-    const int64_t nk = min(nk_all, kb + per_split) - kb;     // K-tiles of this workgroup, numbered 0 .. nk-1 below
-    if (nk <= 0) return;
 
     uint32_t offa[4], offb[4];                       // chunk i = Tile64 i of the operand (rows / columns 64 i ..)
 #pragma unroll
@@ -1038,6 +1095,49 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
     if (wr == 0) __builtin_amdgcn_s_barrier();      // re-align the wave groups
     __syncthreads();
 
+    if constexpr (SK) {
+        int s_ = seg;
+        asm volatile("" : "+s"(s_));
+        const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
+        if (!d.owner) {
+            // unowned head of a tile: publish the raw accumulators (register r of thread t at float4 index r * 512 + t)
+            f32x4* slot = reinterpret_cast<f32x4*>(sk.ws + (size_t)blockIdx.x * STREAMK_SLOT) + tid;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR] = acc[a][b][i][j];
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(sk.flags + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (d.kb > 0) {
+            // the tile was started by the workgroups before this one (same XCD): add what they published
+            for (int c = d.c_first; c < (int)(blockIdx.x >> 3); ++c) {
+                const int wg = (blockIdx.x & 7) + 8 * c;
+                if (tid == 0) {
+                    while (__hip_atomic_load(sk.flags + wg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+                    __hip_atomic_store(sk.flags + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const f32x4* slot = reinterpret_cast<const f32x4*>(sk.ws + (size_t)wg * STREAMK_SLOT) + tid;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[a][b][i][j] += slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR];
+            }
+        }
+    }
+
     // epilogue: per A half, a wave holds 64 rows x (32 + 32) columns, the second 32 columns 128 further right in C.  Two
     // neighbouring waves (wc = 2q, 2q + 1) therefore own the two halves of the same 64-column blocks: they stage both blocks
     // together (one 64 x 64 fp32 piece each) and each writes ONE of them, in whole 128-byte rows of bf16 (256-byte of fp32) -
@@ -1061,23 +1161,79 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
                            csum_carry);
     }
     if (ep.csum) RowWriter<TC>::flush_csum(csum_carry, ep, n0 + 128 * half + 64 * (wc >> 1), N, lane);
+    if constexpr (SK) __syncthreads();               // the staging area is the next segment's first operand buffer
+    }
 }
 
-template <typename TC, typename SrcA, typename SrcB>
+// Partial-sum slots and flags of the stream-K launches, one set per HIP stream (launches on one stream are ordered, launches on
+// different streams may overlap).  Allocated on a stream's first use; never while that stream is being captured into a graph
+// (an allocation is illegal there): such a launch falls back to one tile per workgroup.
+static StreamK streamk_workspace(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<hipStream_t, StreamK> sets;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = sets.find(st);
+    if (it != sets.end()) return it->second;
+    StreamK sk{nullptr, nullptr, 0};
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return sk;                                   // (not remembered: the stream may allocate later)
+    }
+    const size_t flag_bytes = 4096, bytes = STREAMK_WGS * STREAMK_SLOT * sizeof(float) + flag_bytes;
+    char* base = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&base), bytes) == hipSuccess && hipMemset(base, 0, flag_bytes) == hipSuccess &&
+        hipDeviceSynchronize() == hipSuccess) {
+        sk.flags = reinterpret_cast<int*>(base);
+        sk.ws = reinterpret_cast<float*>(base + flag_bytes);
+    } else {
+        (void)hipGetLastError();
+    }
+    sets[st] = sk;
+    return sk;
+}
+
+static std::atomic<int64_t> g_streamk_launches{0};
+
+template <typename TC, typename SrcA, typename SrcB, int ALLOW_SK = 0>     // ALLOW_SK: bit of SHG_STREAMK that enables the split
 static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
                    int split = 1) {
-    const int64_t gm = (M + 255) / 256, gn = (N + 255) / 256;
-    if (gm * gn > 0x7fffffff) return fail_arg("gemm: grid too large");
+    const int64_t gm = (M + 255) / 256, gn = (N + 255) / 256, tiles = gm * gn, nk = K / BK;
+    if (tiles > 0x7fffffff) return fail_arg("gemm: grid too large");
     const size_t lds = std::max<size_t>(2 * 8 * Tile64<bf16_t>::BYTES, (size_t)8 * 64 * STG_LD * 4);
-    auto kern = gemm8_kernel<TC, SrcA, SrcB>;
+    if constexpr (ALLOW_SK) {
+        // stream-K when the even split is worth more than its segment overhead: rounds of whole tiles against the busiest
+        // XCD's share of K-tiles (32 workgroups each), and ranges long enough to hide a second pipeline fill.
+        // SHG_STREAMK: bit 0 conv forward (default on: conv2's 147 tiles 777 -> 620 us, conv1 inside the step 2.18 -> 2.04 ms),
+        // bit 1 conv input gradient (measured slower: 791 -> 859 us), bit 2 conv weight gradient (2x slower: the gathered-B
+        // variant of the segment loop does not keep its registers)
+        static const int streamk = []() { const char* e = getenv("SHG_STREAMK"); return e ? atoi(e) : 1; }();
+        const int64_t per_wg = ((tiles + 7) / 8 * nk + 31) / 32, rounds = (tiles + STREAMK_WGS - 1) / STREAMK_WGS;
+        if ((streamk & ALLOW_SK) && split == 1 && !ep.atomic && per_wg >= 64 && per_wg * 100 <= rounds * nk * 95 && tiles * nk < ((int64_t)1 << 30)) {
+            StreamK sk = streamk_workspace(st);
+            if (sk.ws) {
+                auto kern = gemm8_kernel<TC, SrcA, SrcB, true>;
+                static bool raised_sk = false;               // per instantiation
+                if (!raised_sk) {
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    raised_sk = true;
+                }
+                sk.n_tiles = (int)tiles;
+                g_streamk_launches.fetch_add(1, std::memory_order_relaxed);
+                hipLaunchKernelGGL(kern, dim3(STREAMK_WGS), dim3(512), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn), sk);
+                return check_launch(what);
+            }
+        }
+    }
+    auto kern = gemm8_kernel<TC, SrcA, SrcB, false>;
     static bool raised = false;                      // per instantiation
     if (!raised) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
     if (split > 1) ep.atomic = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn), split), dim3(512), lds, st, sa, sb, ep, M, N, K,
-                       tile_order(gm, gn));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, split), dim3(512), lds, st, sa, sb, ep, M, N, K,
+                       tile_order(gm, gn), StreamK{nullptr, nullptr, 0});
     return check_launch(what);
 }
 
@@ -1249,6 +1405,8 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
 }
 
+extern "C" int64_t shg_gemm_streamk_launches(void) { return shg::g_streamk_launches.load(std::memory_order_relaxed); }
+
 extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
                         int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
                         int accumulate, void* stream) {
@@ -1340,7 +1498,7 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre, 0};
     if (use_gemm8(M, N, K, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2, N * K * 2)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
-        return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
+        return launch8<bf16_t, decltype(sa), decltype(sb), 1>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
     }
     if (use_large(1, M, N, K)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
@@ -1369,7 +1527,7 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
     PlainSrc<bf16_t, false> sa{(const bf16_t*)dy, Cout, 0, Cout, Mo};
     if (use_gemm8(Cout, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
-        return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+        return launch8<float, decltype(sa), decltype(sb), 4>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
     }
     if (use_large(1, Cout, Ncols, Mo)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
@@ -1401,7 +1559,7 @@ extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void*
     Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
     if (Cout % 64 == 0 && use_gemm8(M, N, K, (int64_t)B * Tp * (H + 2) * (W + 2) * Cout * 2, (int64_t)64 * 45 * Cin * 2)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
-        return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
+        return launch8<bf16_t, decltype(sa), decltype(sb), 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
     }
     if (use_large(1, M, N, K)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};

@@ -439,6 +439,41 @@ def test_conv3d_k533_fwd_wgrad_vs_torch(K, dtype, B, T, H, W, Cin, Cout):
     assert torch.allclose(dw2, 2 * dw, rtol=1e-5, atol=1e-6)
 
 
+def test_conv3d_forward_streamk_is_exact_on_integer_data(K):
+    """Conv forward on the stream-K split of the 8-phase kernel (gemm.hip: StreamK; 126 tiles x 180 K-tiles cut into 256 equal
+    ranges, tiles finished by the workgroup that holds their last K-tile).  Small-integer data is exact in fp32, so a lost,
+    doubled or stale partial sum shows; repeated launches check that the flags come back to zero; a second stream gets its
+    own partial-sum slots."""
+    from shg_vqa_amd import _lib
+    B, T, H, W, Cin, Cout = 18, 16, 7, 7, 256, 768
+    gen = torch.Generator().manual_seed(3)
+    x_cl = torch.zeros(B, T, H + 2, W + 2, Cin)
+    x_cl[:, :, 1:-1, 1:-1] = torch.randint(-2, 3, (B, T, H, W, Cin), generator=gen).float()
+    w_cl = torch.randint(-1, 2, (Cout, 5, 3, 3, Cin), generator=gen).float()
+    bias = torch.randint(-3, 4, (Cout,), generator=gen).float()
+    xd, wd = x_cl.to(DEV), w_cl.to(DEV)
+    # exact reference: explicit im2col (windows of the padded channels-last input) x fp32 GEMM on integers
+    To = T - 4
+    sB, sT, sH, sW, sC = xd.stride()
+    win = xd.as_strided((B, To, H, W, 5, 3, 3, Cin), (sB, sT, sH, sW, sT, sH, sW, sC)).reshape(B * To * H * W, 45 * Cin)
+    ref = (win @ wd.reshape(Cout, -1).t() + bias.to(DEV)).bfloat16().float().cpu().view(B, To, H, W, Cout)
+    del win
+    xb, wb, bd = xd.bfloat16(), wd.bfloat16(), bias.to(DEV)
+    before = int(_lib.lib().shg_gemm_streamk_launches())
+    for it in range(3):
+        y = K.conv3d_k533_fwd(xb, wb, bd, act=0)
+        torch.cuda.synchronize()
+        assert torch.equal(y.float().cpu(), ref), it
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y2 = K.conv3d_k533_fwd(xb, wb, bd, act=0)
+    y1 = K.conv3d_k533_fwd(xb, wb, bd, act=0)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.float().cpu(), ref) and torch.equal(y2.float().cpu(), ref)
+    assert int(_lib.lib().shg_gemm_streamk_launches()) == before + 5, "the stream-K path was not taken"
+
+
 @pytest.mark.parametrize("dtype,shape", [(torch.float32, (2, 12, 7, 7, 64, 128)), (torch.bfloat16, (2, 12, 7, 7, 64, 128)),
                                          (torch.bfloat16, (18, 12, 7, 7, 768, 64))])      # 8-phase kernel: 42 x 3 tiles
 def test_conv3d_k533_dgrad_vs_torch(K, dtype, shape):
