@@ -851,45 +851,55 @@ static bool use_gemm4(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t 
     return ((M + 127) / 128) * ((N + 127) / 128) <= max_tiles;
 }
 
-// Stream-K work split of the 8-phase kernel (template parameter SK; the convolutions, whose 147 / 222 / 1 080 tiles fill 57 / 87 /
-// 84 % of the CU-rounds they occupy).  The grid is 8 x 32 workgroups, blockIdx % 8 = the XCD the dispatcher puts a workgroup on.
-// Each XCD owns a contiguous run of output tiles (the same run as in the one-tile-per-workgroup launch: neighbours share operand
-// panels in that XCD's L2) and its 32 workgroups cut the run's K-tiles ("iterations") into 32 equal contiguous ranges.  A range
-// covers the tail of one tile, whole tiles, and the head of the next.  The workgroup whose range holds a tile's LAST iteration
-// owns the tile: it adds the partial sums of the others and runs the epilogue.  A workgroup computes its unowned head segment
-// FIRST and publishes it (fp32, one 256 KiB slot per workgroup, then a flag); owners therefore only wait for workgroups with a
-// lower blockIdx on the same XCD, which were dispatched earlier and never wait before publishing: no deadlock whatever else
-// shares the chip.  The owner clears the flag, so a launch leaves the flags zero.
+// Stream-K work split of the 8-phase kernel (template parameter SK; the conv forward, whose 147 / 222 tiles would leave 43 / 13 %
+// of the CUs idle).  The grid is 8 x 32 workgroups, blockIdx % 8 = the XCD the dispatcher puts a workgroup on.  Each XCD owns a
+// contiguous run of R (16 <= R < 32) output tiles - the same run as in the one-tile-per-workgroup launch - and splits every tile's
+// K-tiles ("iterations") at the same point h = ceil(R nk / 32):
+//   * R HEAD workgroups compute K-tiles [0, h) of one tile each.  They walk K in lockstep like the classic launch, so the tiles
+//     that share an operand panel still read it at the same time and find it in the XCD's L2 (cutting the concatenated
+//     (tile, K) space into 32 contiguous ranges instead balances just as well, but every workgroup then sits at a different K
+//     offset of a different tile: measured 2x the L2-miss traffic);
+//   * 32 - R TAIL workgroups share the remaining [h, nk) of all R tiles, in tile order, as equal contiguous ranges: a tile's
+//     tail is computed by one tail workgroup or cut between two.  They publish raw fp32 partial tiles (slot 2 tile + part)
+//     and set a flag.
+// The head workgroup owns the tile: it adds the one or two published parts to its accumulators and runs the epilogue.  Tail
+// workgroups have the LOWER block indices of their XCD: they are dispatched first and never wait, the heads only wait for
+// them - no deadlock whatever else shares the chip.  The owner clears the flags, so a launch leaves them zero.
 struct StreamK {
     float* ws;
     int* flags;
     int n_tiles;
 };
 constexpr int STREAMK_WGS = 256;
+constexpr int STREAMK_SLOTS = 512;                          // 2 per tile, at most 8 x 31 tiles
 constexpr size_t STREAMK_SLOT = (size_t)256 * 256;          // floats per partial tile
 
 struct StreamKSeg {
-    int tile, kb, nk, owner, c_first;                        // nk == 0: no such segment
-};
+    int tile, kb, nk, owner, slot, parts;                    // nk == 0: no such segment; slot: where a tail segment publishes;
+};                                                           // parts: how many published parts the owner adds
 // segment `seg` of this workgroup (32-bit scalar arithmetic, recomputed where needed instead of kept in registers: the kernel
 // has no register to spare across its main loop)
 __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_all, int seg) {
-    StreamKSeg d{0, 0, 0, 0, 0};
+    StreamKSeg d{0, 0, 0, 0, 0, 0};
     const int n_tiles = sk.n_tiles, xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int wgs = gridDim.x >> 3;
+    const int W = gridDim.x >> 3;
     const int tile0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
-    const int iters = (xq + (xcd < xr ? 1 : 0)) * nk_all, per = (iters + wgs - 1) / wgs;
-    const int lo = min(iters, j * per), hi = min(iters, lo + per);
-    if (hi <= lo) return d;
-    const int lt_first = lo / nk_all, lt_last = (hi - 1) / nk_all;
-    const int head_first = hi % nk_all != 0;                  // the last tile of the range is not finished here: do it first
-    if (seg > lt_last - lt_first) return d;
-    const int lt = head_first ? (seg == 0 ? lt_last : lt_first + seg - 1) : lt_first + seg;
-    d.kb = max(lo, lt * nk_all) - lt * nk_all;
-    d.nk = min(hi, (lt + 1) * nk_all) - lt * nk_all - d.kb;
-    d.owner = d.kb + d.nk == nk_all;
-    d.c_first = (lt * nk_all) / per;
-    d.tile = tile0 + lt;
+    const int R = xq + (xcd < xr ? 1 : 0), T = W - R;          // tiles of this XCD = head workgroups; tail workgroups
+    const int h = min(nk_all, (R * nk_all + W - 1) / W), tl = nk_all - h;     // head / tail length of every tile
+    const int pt = T > 0 ? (R * tl + T - 1) / T : 0;             // tail iterations per tail workgroup
+    if (j >= T) {                                              // head of tile j - T
+        if (seg > 0) return d;
+        const int lt = j - T;
+        d.tile = tile0 + lt; d.kb = 0; d.nk = h; d.owner = 1;
+        d.parts = tl > 0 ? ((lt + 1) * tl - 1) / pt - (lt * tl) / pt + 1 : 0;
+        return d;
+    }
+    const int lo = j * pt, hi = min(lo + pt, R * tl);
+    const int start = seg == 0 ? lo : (lo / tl + seg) * tl;
+    if (tl == 0 || start >= hi) return d;
+    const int lt = start / tl, end = min(hi, (lt + 1) * tl);
+    d.tile = tile0 + lt; d.kb = h + (start - lt * tl); d.nk = end - start; d.owner = 0;
+    d.slot = 2 * d.tile + (start > lt * tl ? 1 : 0);
     return d;
 }
 
@@ -1100,8 +1110,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
         asm volatile("" : "+s"(s_));
         const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
         if (!d.owner) {
-            // unowned head of a tile: publish the raw accumulators (register r of thread t at float4 index r * 512 + t)
-            f32x4* slot = reinterpret_cast<f32x4*>(sk.ws + (size_t)blockIdx.x * STREAMK_SLOT) + tid;
+            // tail segment: publish the raw accumulators (register r of thread t at float4 index r * 512 + t)
+            f32x4* slot = reinterpret_cast<f32x4*>(sk.ws + (size_t)d.slot * STREAMK_SLOT) + tid;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1112,29 +1122,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
                         for (int j = 0; j < 2; ++j) slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR] = acc[a][b][i][j];
             __threadfence();
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(sk.flags + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(sk.flags + d.slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
-        if (d.kb > 0) {
-            // the tile was started by the workgroups before this one (same XCD): add what they published
-            for (int c = d.c_first; c < (int)(blockIdx.x >> 3); ++c) {
-                const int wg = (blockIdx.x & 7) + 8 * c;
-                if (tid == 0) {
-                    while (__hip_atomic_load(sk.flags + wg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
-                    __hip_atomic_store(sk.flags + wg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const f32x4* slot = reinterpret_cast<const f32x4*>(sk.ws + (size_t)wg * STREAMK_SLOT) + tid;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[a][b][i][j] += slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR];
+        // the tile's tail was computed by one or two tail workgroups of this XCD (lower block indices): add what they published
+        for (int part = 0; part < d.parts; ++part) {
+            const int sl = 2 * d.tile + part;
+            if (tid == 0) {
+                while (__hip_atomic_load(sk.flags + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+                __hip_atomic_store(sk.flags + sl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const f32x4* slot = reinterpret_cast<const f32x4*>(sk.ws + (size_t)sl * STREAMK_SLOT) + tid;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[a][b][i][j] += slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR];
         }
     }
 
@@ -1180,7 +1188,7 @@ static StreamK streamk_workspace(hipStream_t st) {
         (void)hipGetLastError();
         return sk;                                   // (not remembered: the stream may allocate later)
     }
-    const size_t flag_bytes = 4096, bytes = STREAMK_WGS * STREAMK_SLOT * sizeof(float) + flag_bytes;
+    const size_t flag_bytes = 4096, bytes = STREAMK_SLOTS * STREAMK_SLOT * sizeof(float) + flag_bytes;
     char* base = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&base), bytes) == hipSuccess && hipMemset(base, 0, flag_bytes) == hipSuccess &&
         hipDeviceSynchronize() == hipSuccess) {
@@ -1208,8 +1216,10 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
         // bit 1 conv input gradient (measured slower: 791 -> 859 us), bit 2 conv weight gradient (2x slower: the gathered-B
         // variant of the segment loop does not keep its registers)
         static const int streamk = []() { const char* e = getenv("SHG_STREAMK"); return e ? atoi(e) : 1; }();
-        const int64_t per_wg = ((tiles + 7) / 8 * nk + 31) / 32, rounds = (tiles + STREAMK_WGS - 1) / STREAMK_WGS;
-        if ((streamk & ALLOW_SK) && split == 1 && !ep.atomic && per_wg >= 64 && per_wg * 100 <= rounds * nk * 95 && tiles * nk < ((int64_t)1 << 30)) {
+        // (every XCD needs 16 <= R < 32 tiles: heads and tails both exist and a tile's tail is cut at most once)
+        const int64_t r_min = tiles / 8, r_max = (tiles + 7) / 8, per_wg = (r_max * nk + 31) / 32;
+        if ((streamk & ALLOW_SK) && split == 1 && !ep.atomic && r_min >= 16 && r_max < 32 && per_wg >= 64 && nk - per_wg >= 8 &&
+            tiles * nk < ((int64_t)1 << 30)) {
             StreamK sk = streamk_workspace(st);
             if (sk.ws) {
                 auto kern = gemm8_kernel<TC, SrcA, SrcB, true>;

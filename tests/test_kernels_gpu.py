@@ -440,12 +440,12 @@ def test_conv3d_k533_fwd_wgrad_vs_torch(K, dtype, B, T, H, W, Cin, Cout):
 
 
 def test_conv3d_forward_streamk_is_exact_on_integer_data(K):
-    """Conv forward on the stream-K split of the 8-phase kernel (gemm.hip: StreamK; 126 tiles x 180 K-tiles cut into 256 equal
-    ranges, tiles finished by the workgroup that holds their last K-tile).  Small-integer data is exact in fp32, so a lost,
+    """Conv forward on the stream-K split of the 8-phase kernel (gemm.hip: StreamK; every tile's K-tiles are split between a
+    head workgroup, which owns the tile, and one or two tail workgroups).  Small-integer data is exact in fp32, so a lost,
     doubled or stale partial sum shows; repeated launches check that the flags come back to zero; a second stream gets its
     own partial-sum slots."""
     from shg_vqa_amd import _lib
-    B, T, H, W, Cin, Cout = 18, 16, 7, 7, 256, 768
+    B, T, H, W, Cin, Cout = 19, 16, 7, 7, 256, 768          # 44 x 3 tiles: 16-17 per XCD (heads), 15-16 tail workgroups
     gen = torch.Generator().manual_seed(3)
     x_cl = torch.zeros(B, T, H + 2, W + 2, Cin)
     x_cl[:, :, 1:-1, 1:-1] = torch.randint(-2, 3, (B, T, H, W, Cin), generator=gen).float()
