@@ -257,7 +257,7 @@ def main():
                                    "(BASELINE.json configs[2]; configs[4] at 8 GPUs)" % B,
                        "global_batch": world * B, "parallelism": "dp%d" % world, "execution": mode},
             "step_mfma_frac": round(qa / world * TRAIN_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"kernel": "gemm8_kernel<bf16, ConvRowSrc, PlainSrc> (shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
+            "roofline": {"kernel": "gemm8_kernel<bf16, ConvRowSrc, PlainSrc, stream-K> (shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(k_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs)},
