@@ -47,6 +47,11 @@ const char* shg_last_error_string(void);
 /* Diagnostics: number of convolution launches so far that used the stream-K work split of the 256 x 256 kernel (gemm.hip:
  * every CU gets the same number of K-tiles).  Tests use it to prove the path was exercised. */
 int64_t shg_gemm_streamk_launches(void);
+/* Host evaluation of that work split for a launch of n_tiles (128..255) output tiles with nk K-tiles each: segment `seg` of
+ * workgroup `block` (0..255) -> out[6] = {tile, first K-tile, number of K-tiles, owner (1: head, runs the epilogue),
+ * partial-sum slot a tail publishes to, number of published parts the owner adds}.  Returns 1, or 0 when the workgroup has no
+ * such segment (SHG_ERR_INVALID on bad arguments).  Pure host arithmetic, no GPU needed. */
+int shg_streamk_plan(int n_tiles, int nk, int block, int seg, int* out);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matcher, per-frame branch.

@@ -20,6 +20,7 @@ _SIGNATURES = {
     "shg_version": ([], c_int),
     "shg_last_error_string": ([], c_char_p),
     "shg_gemm_streamk_launches": ([], L),
+    "shg_streamk_plan": ([I, I, I, I, P], c_int),
     "shg_hungarian_per_frame": ([P, I, I, I, I, P, P, L, P, P, P, P], c_int),
     "shg_lsap_batched": ([P, I, I, I, P, P, P, P], c_int),
     "shg_weighted_ce_fwd": ([P, I, L, I, P, P, L, P, P, P], c_int),

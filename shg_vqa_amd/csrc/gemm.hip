@@ -879,10 +879,10 @@ struct StreamKSeg {
 };                                                           // parts: how many published parts the owner adds
 // segment `seg` of this workgroup (32-bit scalar arithmetic, recomputed where needed instead of kept in registers: the kernel
 // has no register to spare across its main loop)
-__device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_all, int seg) {
+__host__ __device__ __forceinline__ StreamKSeg streamk_plan(int n_tiles, int nk_all, int block, int grid, int seg) {
     StreamKSeg d{0, 0, 0, 0, 0, 0};
-    const int n_tiles = sk.n_tiles, xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int W = gridDim.x >> 3;
+    const int xq = n_tiles / 8, xr = n_tiles % 8, xcd = block & 7, j = block >> 3;
+    const int W = grid >> 3;
     const int tile0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
     const int R = xq + (xcd < xr ? 1 : 0), T = W - R;          // tiles of this XCD = head workgroups; tail workgroups
     const int h = min(nk_all, (R * nk_all + W - 1) / W), tl = nk_all - h;     // head / tail length of every tile
@@ -901,6 +901,9 @@ __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_
     d.tile = tile0 + lt; d.kb = h + (start - lt * tl); d.nk = end - start; d.owner = 0;
     d.slot = 2 * d.tile + (start > lt * tl ? 1 : 0);
     return d;
+}
+__device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_all, int seg) {
+    return streamk_plan(sk.n_tiles, nk_all, (int)blockIdx.x, (int)gridDim.x, seg);
 }
 
 template <typename TC, typename SrcA, typename SrcB, bool SK = false>
@@ -1413,6 +1416,15 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
     }
     Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0, nullptr, nullptr, dthr, dscale, seed_state, stream_id};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
+}
+
+// host evaluation of the device-side work split (tests/test_abi.py checks that heads and tails cover every K-tile of every
+// tile exactly once): out = {tile, first K-tile, K-tiles, owner, slot, parts}; returns 0 when the segment does not exist
+extern "C" int shg_streamk_plan(int n_tiles, int nk, int block, int seg, int* out) {
+    if (!out || n_tiles < 128 || n_tiles >= 256 || nk < 2 || block < 0 || block >= shg::STREAMK_WGS || seg < 0) return shg::fail_arg("streamk_plan: bad argument");
+    const shg::StreamKSeg d = shg::streamk_plan(n_tiles, nk, block, shg::STREAMK_WGS, seg);
+    out[0] = d.tile; out[1] = d.kb; out[2] = d.nk; out[3] = d.owner; out[4] = d.slot; out[5] = d.parts;
+    return d.nk > 0 ? 1 : 0;
 }
 
 extern "C" int64_t shg_gemm_streamk_launches(void) { return shg::g_streamk_launches.load(std::memory_order_relaxed); }

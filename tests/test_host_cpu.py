@@ -156,3 +156,59 @@ def test_clip_targets_packing_matches_reference_converter():
         assert int(n[i]) == len(f.targets)
         assert tgt[i, :len(f.targets)].tolist() == list(f.targets)
         assert (tgt[i, len(f.targets):] == 0).all()
+
+
+def test_streamk_plan_covers_every_k_tile_exactly_once():
+    """The stream-K split of the conv forward (gemm.hip: streamk_plan, evaluated on the host through shg_streamk_plan): for the
+    tile counts and K lengths of the step's convolutions and a sweep around them, heads and tails together cover every K-tile of
+    every output tile exactly once; every tile has exactly one owner, and the owner expects exactly the parts that tail
+    workgroups publish, each to its own slot; tails have lower block indices than every head of their XCD (the no-deadlock
+    argument); all 256 workgroups have work and none more than 7 % above the even share."""
+    import ctypes
+    from shg_vqa_amd import _lib
+    lib = _lib.lib()
+    out = (ctypes.c_int * 6)()
+
+    def plan(n_tiles, nk, block, seg):
+        rc = lib.shg_streamk_plan(n_tiles, nk, block, seg, out)
+        assert rc in (0, 1)
+        return tuple(out) if rc else None
+
+    for n_tiles, nk in [(222, 1440), (147, 540), (132, 180), (128, 64), (255, 97), (200, 333), (129, 1000), (248, 75)]:
+        r_min, r_max = n_tiles // 8, (n_tiles + 7) // 8
+        per_wg = (r_max * nk + 31) // 32
+        if not (r_min >= 16 and r_max < 32 and per_wg >= 64 and nk - per_wg >= 8):
+            continue                                            # (launch8 keeps the one-tile-per-workgroup launch there)
+        cover = [[0] * nk for _ in range(n_tiles)]
+        owners, expected_parts, published, work = {}, {}, {}, []
+        first_head = {}
+        for block in range(256):
+            xcd, total = block & 7, 0
+            for seg in range(64):
+                d = plan(n_tiles, nk, block, seg)
+                if d is None:
+                    break
+                tile, kb, n, owner, slot, parts = d
+                assert 0 <= tile < n_tiles and n > 0 and 0 <= kb and kb + n <= nk
+                for k in range(kb, kb + n):
+                    cover[tile][k] += 1
+                total += n
+                if owner:
+                    assert tile not in owners and kb == 0 and seg == 0
+                    owners[tile] = block
+                    expected_parts[tile] = parts
+                    first_head.setdefault(xcd, block)
+                else:
+                    assert slot in (2 * tile, 2 * tile + 1) and slot not in published and slot < 512
+                    published[slot] = block
+                    assert xcd not in first_head, "a tail workgroup after a head of its XCD"
+            work.append(total)
+        assert all(c == 1 for row in cover for c in row), (n_tiles, nk)
+        assert sorted(owners) == list(range(n_tiles))
+        for tile, parts in expected_parts.items():
+            got = [s for s in (2 * tile, 2 * tile + 1) if s in published]
+            assert got == [2 * tile + p for p in range(parts)], (tile, parts, got)
+            for s in got:                                      # same XCD, lower block index than the owner
+                assert published[s] & 7 == owners[tile] & 7 and published[s] < owners[tile]
+        busy = [w for w in work if w]
+        assert len(busy) == 256 and max(busy) <= 1.07 * n_tiles * nk / 256, (n_tiles, nk, min(busy), max(busy))
