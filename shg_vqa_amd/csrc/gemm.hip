@@ -869,6 +869,7 @@ struct StreamK {
     float* ws;
     int* flags;
     int n_tiles;
+    int sigma;               // cost of a tail K-tile in percent of a head K-tile (tails read their operand panels alone)
 };
 constexpr int STREAMK_WGS = 256;
 constexpr int STREAMK_SLOTS = 512;                          // 2 per tile, at most 8 x 31 tiles
@@ -879,13 +880,15 @@ struct StreamKSeg {
 };                                                           // parts: how many published parts the owner adds
 // segment `seg` of this workgroup (32-bit scalar arithmetic, recomputed where needed instead of kept in registers: the kernel
 // has no register to spare across its main loop)
-__host__ __device__ __forceinline__ StreamKSeg streamk_plan(int n_tiles, int nk_all, int block, int grid, int seg) {
+__host__ __device__ __forceinline__ StreamKSeg streamk_plan(int n_tiles, int nk_all, int block, int grid, int seg, int sigma) {
     StreamKSeg d{0, 0, 0, 0, 0, 0};
     const int xq = n_tiles / 8, xr = n_tiles % 8, xcd = block & 7, j = block >> 3;
     const int W = grid >> 3;
     const int tile0 = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
     const int R = xq + (xcd < xr ? 1 : 0), T = W - R;          // tiles of this XCD = head workgroups; tail workgroups
-    const int h = min(nk_all, (R * nk_all + W - 1) / W), tl = nk_all - h;     // head / tail length of every tile
+    // head / tail length of every tile: heads take h K-tiles, the T tail workgroups R (nk - h) / T each at sigma % of the
+    // heads' speed; equal finishing times give h = sigma R nk / (100 T + sigma R)   (sigma = 100: h = R nk / W)
+    const int h = min(nk_all, (sigma * R * nk_all + 100 * T + sigma * R - 1) / (100 * T + sigma * R)), tl = nk_all - h;
     const int pt = T > 0 ? (R * tl + T - 1) / T : 0;             // tail iterations per tail workgroup
     if (j >= T) {                                              // head of tile j - T
         if (seg > 0) return d;
@@ -903,7 +906,7 @@ __host__ __device__ __forceinline__ StreamKSeg streamk_plan(int n_tiles, int nk_
     return d;
 }
 __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_all, int seg) {
-    return streamk_plan(sk.n_tiles, nk_all, (int)blockIdx.x, (int)gridDim.x, seg);
+    return streamk_plan(sk.n_tiles, nk_all, (int)blockIdx.x, (int)gridDim.x, seg, sk.sigma);
 }
 
 template <typename TC, typename SrcA, typename SrcB, bool SK = false>
@@ -1185,7 +1188,7 @@ static StreamK streamk_workspace(hipStream_t st) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = sets.find(st);
     if (it != sets.end()) return it->second;
-    StreamK sk{nullptr, nullptr, 0};
+    StreamK sk{nullptr, nullptr, 0, 100};
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
@@ -1205,6 +1208,11 @@ static StreamK streamk_workspace(hipStream_t st) {
 }
 
 static std::atomic<int64_t> g_streamk_launches{0};
+static int streamk_sigma() {
+    static const int v = []() { const char* e = getenv("SHG_STREAMK_SIGMA"); const int x = e ? atoi(e) : 112;   // measured: conv1 2246 / 2195 / 2190 / 2204 us, conv2 628 / 580 / 586 / 606 us at 100 / 108 / 116 / 125
+     return x < 100 ? 100 : (x > 200 ? 200 : x); }();
+    return v;
+}
 
 template <typename TC, typename SrcA, typename SrcB, int ALLOW_SK = 0>     // ALLOW_SK: bit of SHG_STREAMK that enables the split
 static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
@@ -1220,7 +1228,8 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
         // variant of the segment loop does not keep its registers)
         static const int streamk = []() { const char* e = getenv("SHG_STREAMK"); return e ? atoi(e) : 1; }();
         // (every XCD needs 16 <= R < 32 tiles: heads and tails both exist and a tile's tail is cut at most once)
-        const int64_t r_min = tiles / 8, r_max = (tiles + 7) / 8, per_wg = (r_max * nk + 31) / 32;
+        const int64_t r_min = tiles / 8, r_max = (tiles + 7) / 8, sg = streamk_sigma();
+        const int64_t per_wg = (sg * r_max * nk + 100 * (32 - r_max) + sg * r_max - 1) / (100 * (32 - r_max) + sg * r_max);   // head length
         if ((streamk & ALLOW_SK) && split == 1 && !ep.atomic && r_min >= 16 && r_max < 32 && per_wg >= 64 && nk - per_wg >= 8 &&
             tiles * nk < ((int64_t)1 << 30)) {
             StreamK sk = streamk_workspace(st);
@@ -1232,6 +1241,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
                     raised_sk = true;
                 }
                 sk.n_tiles = (int)tiles;
+                sk.sigma = (int)sg;
                 g_streamk_launches.fetch_add(1, std::memory_order_relaxed);
                 hipLaunchKernelGGL(kern, dim3(STREAMK_WGS), dim3(512), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn), sk);
                 return check_launch(what);
@@ -1246,7 +1256,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
     }
     if (split > 1) ep.atomic = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, split), dim3(512), lds, st, sa, sb, ep, M, N, K,
-                       tile_order(gm, gn), StreamK{nullptr, nullptr, 0});
+                       tile_order(gm, gn), StreamK{nullptr, nullptr, 0, 100});
     return check_launch(what);
 }
 
@@ -1422,7 +1432,7 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
 // tile exactly once): out = {tile, first K-tile, K-tiles, owner, slot, parts}; returns 0 when the segment does not exist
 extern "C" int shg_streamk_plan(int n_tiles, int nk, int block, int seg, int* out) {
     if (!out || n_tiles < 128 || n_tiles >= 256 || nk < 2 || block < 0 || block >= shg::STREAMK_WGS || seg < 0) return shg::fail_arg("streamk_plan: bad argument");
-    const shg::StreamKSeg d = shg::streamk_plan(n_tiles, nk, block, shg::STREAMK_WGS, seg);
+    const shg::StreamKSeg d = shg::streamk_plan(n_tiles, nk, block, shg::STREAMK_WGS, seg, shg::streamk_sigma());
     out[0] = d.tile; out[1] = d.kb; out[2] = d.nk; out[3] = d.owner; out[4] = d.slot; out[5] = d.parts;
     return d.nk > 0 ? 1 : 0;
 }

@@ -168,6 +168,8 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
     from shg_vqa_amd import _lib
     lib = _lib.lib()
     out = (ctypes.c_int * 6)()
+    # heads get sigma % of an even share (tail workgroups read their operand panels alone and are slower; gemm.hip: streamk_sigma)
+    sigma = min(200, max(100, int(os.environ.get("SHG_STREAMK_SIGMA", "112"))))
 
     def plan(n_tiles, nk, block, seg):
         rc = lib.shg_streamk_plan(n_tiles, nk, block, seg, out)
@@ -176,7 +178,8 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
 
     for n_tiles, nk in [(222, 1440), (147, 540), (132, 180), (128, 64), (255, 97), (200, 333), (129, 1000), (248, 75)]:
         r_min, r_max = n_tiles // 8, (n_tiles + 7) // 8
-        per_wg = (r_max * nk + 31) // 32
+        den = 100 * (32 - r_max) + sigma * r_max
+        per_wg = (sigma * r_max * nk + den - 1) // den         # head length on the fullest XCD
         if not (r_min >= 16 and r_max < 32 and per_wg >= 64 and nk - per_wg >= 8):
             continue                                            # (launch8 keeps the one-tile-per-workgroup launch there)
         cover = [[0] * nk for _ in range(n_tiles)]
@@ -211,4 +214,4 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
             for s in got:                                      # same XCD, lower block index than the owner
                 assert published[s] & 7 == owners[tile] & 7 and published[s] < owners[tile]
         busy = [w for w in work if w]
-        assert len(busy) == 256 and max(busy) <= 1.07 * n_tiles * nk / 256, (n_tiles, nk, min(busy), max(busy))
+        assert len(busy) == 256 and max(busy) <= 1.07 * sigma / 100 * n_tiles * nk / 256, (n_tiles, nk, min(busy), max(busy))
