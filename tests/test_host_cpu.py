@@ -215,3 +215,16 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
                 assert published[s] & 7 == owners[tile] & 7 and published[s] < owners[tile]
         busy = [w for w in work if w]
         assert len(busy) == 256 and max(busy) <= 1.07 * sigma / 100 * n_tiles * nk / 256, (n_tiles, nk, min(busy), max(busy))
+
+
+def test_bench_constants_follow_the_survey_flop_table():
+    """bench.py prices its fractions with SURVEY section 8(d): 428.21 / 178.79 / 45.50 GFLOP per QA pair (training, forward, the
+    attention stack's forward) and conv1 = 83.236 GFLOP per QA pair = 2 x (12 x 49) x 768 x (45 x 2048) flop."""
+    import bench
+    assert bench.PEAK_BF16_TFLOPS == 2500.0
+    assert (bench.TRAIN_GFLOP_PER_QA, bench.FWD_GFLOP_PER_QA, bench.STACK_FWD_GFLOP_PER_QA) == (428.21, 178.79, 45.50)
+    conv1 = 2.0 * (12 * 49) * 768 * (45 * 2048)
+    assert abs(conv1 / 1e9 - 83.236) < 1e-3
+    # per-layer formulas of the same table: BertLayer(S) = S (4 H^2 + 2 H F) + 2 S^2 H MAC with H = 768, F = 3072
+    layer = lambda S: 2.0 * (S * (4 * 768 ** 2 + 2 * 768 * 3072) + 2 * S * S * 768) / 1e9
+    assert abs(5 * layer(40) - 2.856) < 2e-3 and abs(5 * layer(393) - 30.188) < 2e-3
