@@ -854,7 +854,7 @@ static bool use_gemm4(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t 
 // Stream-K work split of the 8-phase kernel (template parameter SK; the conv forward, whose 147 / 222 tiles would leave 43 / 13 %
 // of the CUs idle).  The grid is 8 x 32 workgroups, blockIdx % 8 = the XCD the dispatcher puts a workgroup on.  Each XCD owns a
 // contiguous run of R (16 <= R < 32) output tiles - the same run as in the one-tile-per-workgroup launch - and splits every tile's
-// K-tiles ("iterations") at the same point h = ceil(R nk / 32):
+// K-tiles ("iterations") at the same point h (an even share would be ceil(R nk / 32); see sigma below):
 //   * R HEAD workgroups compute K-tiles [0, h) of one tile each.  They walk K in lockstep like the classic launch, so the tiles
 //     that share an operand panel still read it at the same time and find it in the XCD's L2 (cutting the concatenated
 //     (tile, K) space into 32 contiguous ranges instead balances just as well, but every workgroup then sits at a different K
@@ -1231,7 +1231,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
         const int64_t r_min = tiles / 8, r_max = (tiles + 7) / 8, sg = streamk_sigma();
         const int64_t per_wg = (sg * r_max * nk + 100 * (32 - r_max) + sg * r_max - 1) / (100 * (32 - r_max) + sg * r_max);   // head length
         if ((streamk & ALLOW_SK) && split == 1 && !ep.atomic && r_min >= 16 && r_max < 32 && per_wg >= 64 && nk - per_wg >= 8 &&
-            tiles * nk < ((int64_t)1 << 30)) {
+            tiles * nk < ((int64_t)1 << 23)) {             // (32-bit plan arithmetic: sigma R nk stays below 2^31)
             StreamK sk = streamk_workspace(st);
             if (sk.ws) {
                 auto kern = gemm8_kernel<TC, SrcA, SrcB, true>;
