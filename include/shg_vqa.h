@@ -263,6 +263,136 @@ int shg_add_i64(int64_t* p, int64_t delta, void* stream);
 /* dst(dtype) = cast(src fp32), n elements */
 int shg_cast_f32(const float* src, void* dst, int dtype, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Small elementwise helpers of the decoder executor (transformer.py:213-226: `tgt + query_pos`, and its backward).
+ *   shg_add:             out[i] = a[i] + b[i]                                   (n elements of dtype, n % 8 == 0)
+ *   shg_add2_accumulate: acc1[i] += c[i];  acc2[i] = init2 ? c[i] : acc2[i] + c[i]   (acc1 may be NULL)
+ * Sums are formed in fp32 and rounded once. */
+int shg_add(const void* a, const void* b, void* out, int dtype, int64_t n, void* stream);
+int shg_add2_accumulate(void* acc1, void* acc2, const void* c, int init2, int dtype, int64_t n, void* stream);
+
+/* shg_bias_act_drop_res_ln_fwd with a second output y_pos = y + pos (pos, y_pos [rows, cols] (dtype), both NULL or both set):
+ * the decoder feeds `tgt + query_pos` into the next attention's projections (transformer.py:216, :222), so the LayerNorm that
+ * produces tgt writes the sum in the same pass. */
+int shg_bias_act_drop_res_ln_fwd_pos(const void* x, const float* bias, const void* residual, const float* gamma,
+                                     const float* beta, void* y, void* z_out, float* mean, float* rstd, const void* pos,
+                                     void* y_pos, int dtype, int64_t rows, int cols, int act, float eps, float p_drop,
+                                     const uint64_t* seed_state, uint64_t stream_id, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sub-layer executor: ONE call enqueues every kernel of a transformer sub-layer (6-16 launches), so that the host
+ * issues ~100 calls per training step instead of ~1 150 (the decoder / hyper-graph segments of the step run at the
+ * host's pace otherwise).  The arithmetic is exactly the sequence of entry points above; nothing here computes.
+ *
+ *   shg_exec_t     caller-owned handle: a ring of hipEvents used to order the weight-gradient stream behind the main
+ *                  stream (create once per device; destroy at exit).  The library keeps no global state for it.
+ *   shg_run_t      per-call context: streams, dropout seed, dtype.
+ *   shg_linear_t   one nn.Linear: operand copy of the weight in the compute dtype (the bf16 shadow or the fp32 master),
+ *                  fp32 bias, and the fp32 gradient slices (NULL: parameter does not train).
+ *   shg_norm_t     one nn.LayerNorm.
+ * Activations are row-major [rows, features] in `dtype`, contiguous, 16-byte aligned.  `saved` (forward -> backward) and
+ * `scratch` (backward temporaries, also read by the weight-gradient stream after the call returns: give every call its
+ * own) are caller-owned device buffers of shg_*_saved_bytes / shg_*_scratch_bytes bytes.
+ * Weight / bias / LayerNorm gradients are ACCUMULATED into the gradient slices (on run->wgrad_stream when set).
+ * Dropout call sites: each sub-layer uses stream ids sid and sid + 1; a decoder layer uses sid .. sid + 5.
+ */
+typedef struct shg_exec shg_exec_t;
+/* sizeof() of the structs below as this library was compiled, for bindings that mirror them:
+ * which = 0 shg_run_t, 1 shg_linear_t, 2 shg_norm_t, 3 shg_attn_sublayer_t, 4 shg_ffn_sublayer_t, 5 shg_decoder_layer_t */
+int shg_abi_sizeof(int which);
+shg_exec_t* shg_exec_create(int n_events);
+void shg_exec_destroy(shg_exec_t* ex);
+
+typedef struct shg_run {
+    int32_t dtype;            /* SHG_F32 / SHG_BF16: activations and operands */
+    int32_t training;         /* 0: every dropout probability is taken as 0 */
+    void* stream;             /* hipStream_t of the dependent chain */
+    void* wgrad_stream;       /* hipStream_t for weight gradients, or NULL: inline on `stream` */
+    shg_exec_t* exec;         /* needed when wgrad_stream is set */
+    const uint64_t* seed_state;
+} shg_run_t;
+
+typedef struct shg_linear {
+    const void* w;            /* [out, in] row-major, compute dtype */
+    const float* bias;        /* [out] or NULL */
+    float* gw;                /* [out, in] fp32 gradient or NULL */
+    float* gb;                /* [out] fp32 gradient or NULL */
+} shg_linear_t;
+
+typedef struct shg_norm {
+    const float* gamma;
+    const float* beta;
+    float* g_gamma;           /* NULL: does not train */
+    float* g_beta;
+    float eps;
+    float pad_;
+} shg_norm_t;
+
+#define SHG_ATTN_SELF 0       /* q,k,v = W_a x (W_a [3H,H]);                    BertSelfattLayer, modeling_capsbert.py:450-460 */
+#define SHG_ATTN_CROSS 1      /* q = W_a x (W_a [H,H]); k,v = W_b mem (W_b [2H,H]);  BertCrossattLayer, modeling_capsbert.py:438-447 */
+#define SHG_ATTN_DEC_SELF 2   /* q,k = W_a (x+pos) (W_a [2H,H]); v = W_b x (W_b [H,H]);  transformer.py:216-221 */
+#define SHG_ATTN_DEC_CROSS 3  /* q = W_a (x+pos); k,v = W_b mem;                  transformer.py:222-227 */
+
+/* y = LayerNorm(x + dropout(W_o attention(...) + b_o))   (BertAttention + BertAttOutput, modeling_capsbert.py:384-435;
+ * nn.MultiheadAttention + dropout + norm of the DETR decoder layer, transformer.py:216-227) */
+typedef struct shg_attn_sublayer {
+    int32_t mode;             /* SHG_ATTN_* */
+    int32_t heads;            /* hidden = heads * 64 */
+    int32_t mask_kind;        /* SHG_MASK_* */
+    int32_t pad_;
+    float scale, p_attn, p_out, pad2_;
+    const float* mask;        /* per mask_kind */
+    shg_linear_t a, b, o;
+    shg_norm_t ln;
+} shg_attn_sublayer_t;
+
+/* y = LayerNorm(x + dropout(W_2 dropout(act(W_1 x + b_1)) + b_2))   (BertIntermediate + BertOutput,
+ * modeling_capsbert.py:463-489; linear1 / ReLU / dropout / linear2 / dropout3 / norm3, transformer.py:230-232) */
+typedef struct shg_ffn_sublayer {
+    int32_t act;              /* SHG_ACT_* */
+    int32_t pad_;
+    float p_inner, p_out;
+    shg_linear_t l1, l2;      /* l1 [F, H], l2 [H, F] */
+    shg_norm_t ln;
+} shg_ffn_sublayer_t;
+
+typedef struct shg_decoder_layer {
+    shg_attn_sublayer_t self_attn, cross_attn;     /* modes SHG_ATTN_DEC_SELF / SHG_ATTN_DEC_CROSS */
+    shg_ffn_sublayer_t ffn;
+} shg_decoder_layer_t;
+
+/* x [B*Sq, H]; xpos = x + pos (decoder modes, else NULL); mem [B*Sk, H] (cross modes, else NULL; Sk = Sq then);
+ * y [B*Sq, H]; pos / y_pos: optional second output y + pos (both NULL or both set). */
+int64_t shg_attn_sublayer_saved_bytes(int mode, int dtype, int B, int Sq, int Sk, int heads);
+int64_t shg_attn_sublayer_scratch_bytes(int mode, int dtype, int B, int Sq, int Sk, int heads);
+int shg_attn_sublayer_fwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int Sq, int Sk, const void* x,
+                          const void* xpos, const void* mem, void* y, const void* pos, void* y_pos, void* saved,
+                          uint64_t sid);
+/* dy [B*Sq, H] -> dx (gradient w.r.t. x: residual path + projections; NULL: not needed), dxpos (gradient w.r.t. xpos,
+ * decoder modes; NULL: not needed), dmem (cross modes; NULL: not needed; dmem_accumulate != 0 adds into it). */
+int shg_attn_sublayer_bwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int Sq, int Sk, const void* x,
+                          const void* xpos, const void* mem, const void* saved, const void* dy, void* dx, void* dxpos,
+                          void* dmem, int dmem_accumulate, void* scratch, uint64_t sid);
+
+int64_t shg_ffn_sublayer_saved_bytes(int dtype, int64_t rows, int H, int F);
+int64_t shg_ffn_sublayer_scratch_bytes(int dtype, int64_t rows, int H, int F);
+int shg_ffn_sublayer_fwd(const shg_ffn_sublayer_t* L, const shg_run_t* R, int64_t rows, int H, int F, const void* x, void* y,
+                         const void* pos, void* y_pos, void* saved, uint64_t sid);
+int shg_ffn_sublayer_bwd(const shg_ffn_sublayer_t* L, const shg_run_t* R, int64_t rows, int H, int F, const void* x,
+                         const void* saved, const void* dy, void* dx, void* scratch, uint64_t sid);
+
+/* n_layers DETR decoder layers (post-norm, transformer.py:86-124, :212-233) in one call:
+ *   tgt [B*Q, H] or NULL (= zeros, agqa_model.py:234), memory [B*S, H], query_pos [B*Q, H]; the block-causal target mask
+ *   (entry.py:114-121) sits in every layer's self_attn.mask; out [B*Q, H] = the last layer's output.
+ * bwd: d_out -> d_tgt (NULL when tgt was NULL or not needed), d_query_pos, d_memory (both written, not accumulated). */
+int64_t shg_decoder_saved_bytes(int n_layers, int dtype, int B, int Q, int S, int heads, int F);
+int64_t shg_decoder_scratch_bytes(int n_layers, int dtype, int B, int Q, int S, int heads, int F);
+int shg_decoder_fwd(const shg_decoder_layer_t* layers, int n_layers, const shg_run_t* R, int B, int Q, int S, int F,
+                    const void* tgt, const void* memory, const void* query_pos, void* out, void* saved, uint64_t sid);
+int shg_decoder_bwd(const shg_decoder_layer_t* layers, int n_layers, const shg_run_t* R, int B, int Q, int S, int F,
+                    const void* tgt, const void* memory, const void* query_pos, const void* saved, const void* d_out,
+                    void* d_tgt, void* d_query_pos, void* d_memory, void* scratch, uint64_t sid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,7 +51,58 @@ _SIGNATURES = {
     "shg_bertadam_arena": ([P, P, P, P, P, L, P, F, F, F, L, F, F, F, F, P, I, P], c_int),
     "shg_add_i64": ([P, L, P], c_int),
     "shg_cast_f32": ([P, P, I, L, P], c_int),
+    "shg_add": ([P, P, P, I, L, P], c_int),
+    "shg_add2_accumulate": ([P, P, P, I, I, L, P], c_int),
+    "shg_bias_act_drop_res_ln_fwd_pos": ([P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, F, F, P, U, P], c_int),
+    "shg_exec_create": ([I], c_void_p),
+    "shg_exec_destroy": ([P], None),
+    "shg_abi_sizeof": ([I], c_int),
+    "shg_attn_sublayer_saved_bytes": ([I, I, I, I, I, I], c_int64),
+    "shg_attn_sublayer_scratch_bytes": ([I, I, I, I, I, I], c_int64),
+    "shg_attn_sublayer_fwd": ([P, P, I, I, I, P, P, P, P, P, P, P, U], c_int),
+    "shg_attn_sublayer_bwd": ([P, P, I, I, I, P, P, P, P, P, P, P, P, I, P, U], c_int),
+    "shg_ffn_sublayer_saved_bytes": ([I, L, I, I], c_int64),
+    "shg_ffn_sublayer_scratch_bytes": ([I, L, I, I], c_int64),
+    "shg_ffn_sublayer_fwd": ([P, P, L, I, I, P, P, P, P, P, U], c_int),
+    "shg_ffn_sublayer_bwd": ([P, P, L, I, I, P, P, P, P, P, U], c_int),
+    "shg_decoder_saved_bytes": ([I, I, I, I, I, I, I], c_int64),
+    "shg_decoder_scratch_bytes": ([I, I, I, I, I, I, I], c_int64),
+    "shg_decoder_fwd": ([P, I, P, I, I, I, I, P, P, P, P, P, U], c_int),
+    "shg_decoder_bwd": ([P, I, P, I, I, I, I, P, P, P, P, P, P, P, P, P, U], c_int),
 }
+
+
+# ---- structs of the sub-layer executor (include/shg_vqa.h); sizes are checked against the library at load time
+class LinearT(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("gw", c_void_p), ("gb", c_void_p)]
+
+
+class NormT(ctypes.Structure):
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("g_gamma", c_void_p), ("g_beta", c_void_p), ("eps", c_float),
+                ("pad_", c_float)]
+
+
+class AttnSublayerT(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("heads", ctypes.c_int32), ("mask_kind", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("scale", c_float), ("p_attn", c_float), ("p_out", c_float), ("pad2_", c_float), ("mask", c_void_p),
+                ("a", LinearT), ("b", LinearT), ("o", LinearT), ("ln", NormT)]
+
+
+class FfnSublayerT(ctypes.Structure):
+    _fields_ = [("act", ctypes.c_int32), ("pad_", ctypes.c_int32), ("p_inner", c_float), ("p_out", c_float), ("l1", LinearT),
+                ("l2", LinearT), ("ln", NormT)]
+
+
+class DecoderLayerT(ctypes.Structure):
+    _fields_ = [("self_attn", AttnSublayerT), ("cross_attn", AttnSublayerT), ("ffn", FfnSublayerT)]
+
+
+class RunT(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("training", ctypes.c_int32), ("stream", c_void_p), ("wgrad_stream", c_void_p),
+                ("exec", c_void_p), ("seed_state", c_void_p)]
+
+
+_ABI_STRUCTS = [RunT, LinearT, NormT, AttnSublayerT, FfnSublayerT, DecoderLayerT]
 
 _lib = None
 
@@ -79,6 +130,9 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = args
             fn.restype = ret
+        for i, st in enumerate(_ABI_STRUCTS):
+            if handle.shg_abi_sizeof(i) != ctypes.sizeof(st):
+                raise ShgError("struct layout mismatch with libshgvqa.so for %s: rebuild (python -m shg_vqa_amd.build)" % st.__name__)
         _lib = handle
     return _lib
 

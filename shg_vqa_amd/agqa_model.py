@@ -58,17 +58,7 @@ class HGDecoder(nn.Module):
         def decode(emb, dec, seg, per):
             qpos = emb(seg)
             mask = rel_target_mask_device(self.num_situations, per, dev)
-            E = engine()
-            if (E.graph_decoders and E.training and torch.is_grad_enabled() and memory.requires_grad
-                    and not torch.cuda.is_current_stream_capturing()):
-                # the decoder's ~80 forward / ~200 backward launches as two hipGraph replays (graphed.py)
-                key = (id(dec), tuple(memory.shape), tuple(qpos.shape), memory.dtype)
-                segs = self.__dict__.setdefault("_graphed", {})
-                if key not in segs:
-                    from .graphed import GraphedSegment
-                    segs[key] = GraphedSegment(lambda m, q: dec.forward_bf(torch.zeros_like(q), m, q, mask), [memory, qpos])
-                return segs[key](memory, qpos)
-            return dec.forward_bf(torch.zeros_like(qpos), memory, qpos, mask)
+            return dec.forward_bf(None, memory, qpos, mask)          # tgt = zeros (agqa_model.py:234)
 
         # the two decoders only share `memory`: the action decoder runs on a side stream beside the
         # relation decoder (both are chains of small launches that leave most of the GPU idle)
@@ -170,7 +160,7 @@ class AGQAModel(nn.Module):
         for name, mod in self.named_modules():
             if isinstance(mod, M.BertAttention):
                 groups += mod.fusion_groups(name + ".")
-            for slot in ("_fz", "_ap", "_fp", "_fl", "_fv", "_sp"):      # cached operand handles refer to arena offsets
+            for slot in ("_fz", "_ap", "_fp", "_fl", "_fv", "_sp", "_dp"):      # cached operand handles refer to arena offsets
                 if slot in mod.__dict__:
                     mod.__dict__[slot] = None
         # shared modules are registered under several names: keep the groups whose names are canonical

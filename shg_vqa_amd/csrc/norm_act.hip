@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const T* __restrict__ residual, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      T* __restrict__ z_out, float* __restrict__ mean_out,
-                                                     float* __restrict__ rstd_out, int64_t rows, int cols, float eps,
+                                                     float* __restrict__ rstd_out, const T* __restrict__ pos,
+                                                     T* __restrict__ y_pos, int64_t rows, int cols, float eps,
                                                      uint32_t drop_thr, float drop_scale,
                                                      const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
     constexpr int V = Vec16<T>::N;
@@ -105,6 +106,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
             for (int j = 0; j < V; ++j) yo.set(j, (zv[i][j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j]);
             store16(y + row * cols + c0, yo);
+            if (y_pos) {                 // second output: y (as stored) + pos, rounded once (the decoder's `tgt + query_pos`)
+                const Vec16<T> pv = load16(pos + row * cols + c0);
+                Vec16<T> po;
+#pragma unroll
+                for (int j = 0; j < V; ++j) po.set(j, yo.get(j) + pv.get(j));
+                store16(y_pos + row * cols + c0, po);
+            }
         }
     }
 }
@@ -394,7 +402,7 @@ template <typename T> static bool aligned16(const T* p) { return (reinterpret_ca
 
 template <typename T>
 static int launch_ln_fwd(const void* x, const float* bias, const void* residual, const float* gamma, const float* beta,
-                         void* y, void* z_out, float* mean, float* rstd, int64_t rows, int cols, int act, float eps,
+                         void* y, void* z_out, float* mean, float* rstd, const void* pos, void* y_pos, int64_t rows, int cols, int act, float eps,
                          float p_drop, const uint64_t* seed_state, uint64_t stream_id, hipStream_t st) {
     const uint32_t thr = dropout_threshold(p_drop);
     const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -402,7 +410,7 @@ static int launch_ln_fwd(const void* x, const float* bias, const void* residual,
     const int nch = (cols / Vec16<T>::N + 63) / 64;
 #define LN_FWD2(ACT, NCH)                                                                                             \
     hipLaunchKernelGGL((ln_fwd_kernel<T, ACT, NCH>), grid, block, 0, st, (const T*)x, bias, (const T*)residual, gamma, \
-                       beta, (T*)y, (T*)z_out, mean, rstd, rows, cols, eps, thr, scale, seed_state, stream_id)
+                       beta, (T*)y, (T*)z_out, mean, rstd, (const T*)pos, (T*)y_pos, rows, cols, eps, thr, scale, seed_state, stream_id)
 #define LN_FWD(ACT) do { if (nch <= 2) LN_FWD2(ACT, 2); else if (nch <= 4) LN_FWD2(ACT, 4); else LN_FWD2(ACT, 8); } while (0)
     if (act == SHG_ACT_NONE) LN_FWD(SHG_ACT_NONE);
     else if (act == SHG_ACT_GELU) LN_FWD(SHG_ACT_GELU);
@@ -508,20 +516,102 @@ extern "C" int shg_colsum_finish_multi(const float* const* partials, float* cons
     return check_launch("colsum_finish_multi");
 }
 
+extern "C" int shg_bias_act_drop_res_ln_fwd_pos(const void* x, const float* bias, const void* residual, const float* gamma,
+                                                const float* beta, void* y, void* z_out, float* mean, float* rstd,
+                                                const void* pos, void* y_pos, int dtype, int64_t rows, int cols, int act,
+                                                float eps, float p_drop, const uint64_t* seed_state, uint64_t stream_id,
+                                                void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return fail_arg("ln_fwd: null pointer");
+    if ((pos == nullptr) != (y_pos == nullptr)) return fail_arg("ln_fwd: pos and y_pos go together");
+    if (int e = check_cols(dtype, cols, "ln_fwd: cols must be a multiple of the 16-byte vector and <= 2048 (f32) / 4096 (bf16)")) return e;
+    if (!aligned16(x) || !aligned16(y) || (residual && !aligned16(residual)) || (z_out && !aligned16(z_out)) ||
+        (pos && (!aligned16(pos) || !aligned16(y_pos))))
+        return fail_arg("ln_fwd: pointers must be 16-byte aligned");
+    if (act < 0 || act > 2 || p_drop < 0.f || p_drop >= 1.f) return fail_arg("ln_fwd: bad act/p_drop");
+    if (p_drop > 0.f && !seed_state) return fail_arg("ln_fwd: dropout needs seed_state");
+    if (rows <= 0) return rows == 0 ? 0 : fail_arg("ln_fwd: negative rows");
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == SHG_F32
+               ? launch_ln_fwd<float>(x, bias, residual, gamma, beta, y, z_out, mean, rstd, pos, y_pos, rows, cols, act, eps, p_drop, seed_state, stream_id, st)
+               : launch_ln_fwd<bf16_t>(x, bias, residual, gamma, beta, y, z_out, mean, rstd, pos, y_pos, rows, cols, act, eps, p_drop, seed_state, stream_id, st);
+}
+
 extern "C" int shg_bias_act_drop_res_ln_fwd(const void* x, const float* bias, const void* residual, const float* gamma,
                                             const float* beta, void* y, void* z_out, float* mean, float* rstd,
                                             int dtype, int64_t rows, int cols, int act, float eps, float p_drop,
                                             const uint64_t* seed_state, uint64_t stream_id, void* stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd) return fail_arg("ln_fwd: null pointer");
-    if (int e = check_cols(dtype, cols, "ln_fwd: cols must be a multiple of the 16-byte vector and <= 2048 (f32) / 4096 (bf16)")) return e;
-    if (!aligned16(x) || !aligned16(y) || (residual && !aligned16(residual)) || (z_out && !aligned16(z_out)))
-        return fail_arg("ln_fwd: pointers must be 16-byte aligned");
-    if (act < 0 || act > 2 || p_drop < 0.f || p_drop >= 1.f) return fail_arg("ln_fwd: bad act/p_drop");
-    if (rows <= 0) return rows == 0 ? 0 : fail_arg("ln_fwd: negative rows");
+    return shg_bias_act_drop_res_ln_fwd_pos(x, bias, residual, gamma, beta, y, z_out, mean, rstd, nullptr, nullptr, dtype, rows,
+                                            cols, act, eps, p_drop, seed_state, stream_id, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise helpers of the decoder executor
+// ------------------------------------------------------------------------------------------------
+namespace shg {
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n_vec) {
+    constexpr int V = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+        const Vec16<T> av = load16(a + i * V), bv = load16(b + i * V);
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.set(j, av.get(j) + bv.get(j));
+        store16(out + i * V, o);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void add2_kernel(T* __restrict__ acc1, T* __restrict__ acc2, const T* __restrict__ c, int init2,
+                                                   int64_t n_vec) {
+    constexpr int V = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+        const Vec16<T> cv = load16(c + i * V);
+        if (acc1) {
+            const Vec16<T> a = load16(acc1 + i * V);
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) o.set(j, a.get(j) + cv.get(j));
+            store16(acc1 + i * V, o);
+        }
+        if (!acc2) continue;
+        if (init2) {
+            store16(acc2 + i * V, cv);
+        } else {
+            const Vec16<T> a = load16(acc2 + i * V);
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) o.set(j, a.get(j) + cv.get(j));
+            store16(acc2 + i * V, o);
+        }
+    }
+}
+}  // namespace shg
+
+extern "C" int shg_add(const void* a, const void* b, void* out, int dtype, int64_t n, void* stream) {
+    if (!a || !b || !out) return fail_arg("add: null pointer");
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("add: bad dtype");
+    const int V = dtype == SHG_BF16 ? 8 : 4;
+    if (n <= 0 || n % V) return n == 0 ? 0 : fail_arg("add: n must be a positive multiple of the 16-byte vector");
+    if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return fail_arg("add: pointers must be 16-byte aligned");
+    const int64_t n_vec = n / V;
+    dim3 grid((unsigned)std::min<int64_t>((n_vec + 255) / 256, 4096)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    return dtype == SHG_F32
-               ? launch_ln_fwd<float>(x, bias, residual, gamma, beta, y, z_out, mean, rstd, rows, cols, act, eps, p_drop, seed_state, stream_id, st)
-               : launch_ln_fwd<bf16_t>(x, bias, residual, gamma, beta, y, z_out, mean, rstd, rows, cols, act, eps, p_drop, seed_state, stream_id, st);
+    if (dtype == SHG_F32) hipLaunchKernelGGL(add_kernel<float>, grid, block, 0, st, (const float*)a, (const float*)b, (float*)out, n_vec);
+    else hipLaunchKernelGGL(add_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n_vec);
+    return check_launch("add");
+}
+
+extern "C" int shg_add2_accumulate(void* acc1, void* acc2, const void* c, int init2, int dtype, int64_t n, void* stream) {
+    if ((!acc1 && !acc2) || !c) return fail_arg("add2: null pointer");
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("add2: bad dtype");
+    const int V = dtype == SHG_BF16 ? 8 : 4;
+    if (n <= 0 || n % V) return n == 0 ? 0 : fail_arg("add2: n must be a positive multiple of the 16-byte vector");
+    if ((acc1 && !aligned16(acc1)) || (acc2 && !aligned16(acc2)) || !aligned16(c)) return fail_arg("add2: pointers must be 16-byte aligned");
+    const int64_t n_vec = n / V;
+    dim3 grid((unsigned)std::min<int64_t>((n_vec + 255) / 256, 4096)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) hipLaunchKernelGGL(add2_kernel<float>, grid, block, 0, st, (float*)acc1, (float*)acc2, (const float*)c, init2, n_vec);
+    else hipLaunchKernelGGL(add2_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)acc1, (bf16_t*)acc2, (const bf16_t*)c, init2, n_vec);
+    return check_launch("add2");
 }
 
 extern "C" int shg_bias_act_drop_res_ln_bwd(const void* dy, const void* z, const void* x, const float* bias,

@@ -14,6 +14,7 @@ element offset.  Consequences:
     permuted view, so checkpoints keep the reference's keys and shapes.
 nn.Parameters become views into the arenas; `p.grad` is a persistent view of the gradient arena.
 """
+import ctypes
 import os
 
 import torch
@@ -65,8 +66,8 @@ class Engine:
         self.defer_x_layers = False
         self.deferred_branch = None
         self.grad_dirty = False           # gradients written since the arena was last zeroed
-        self.capture_segment = None       # graphed.GraphedSegment whose backward is being captured
-        self.graph_decoders = os.environ.get("SHG_GRAPH_DECODERS", "0") != "0"   # hipGraph replay of the decoders (graphed.py)
+        self._exec = None                 # shg_exec_t* of the sub-layer executor (event ring for the weight-gradient stream)
+        self._run = None                  # persistent shg_run_t handed to every executor call
         self.params_ready_event = None
         # set per call by AGQA.train_step(overlap_update=True): the caller then waits (wait_params_ready / a device
         # synchronisation / the next train_step) before it reads parameters on another stream
@@ -91,6 +92,43 @@ class Engine:
     def next_stream_id(self):
         self._stream_id += 1
         return self._stream_id
+
+    def take_stream_ids(self, n):
+        """First of n consecutive dropout call-site ids (the sub-layer executor numbers its call sites itself)."""
+        first = self._stream_id + 1
+        self._stream_id += n
+        return first
+
+    # ------------------------------------------------------------------ sub-layer executor context
+    def run_addr(self, dtype_code):
+        """Address of the shg_run_t for an executor call issued NOW: torch's current stream, the weight-gradient side
+        stream (if enabled), dropout on / off."""
+        from . import _lib
+        from .kernels import _stream
+        R = self._run
+        if R is None:
+            R = self._run = _lib.RunT()
+            h = _lib.lib().shg_exec_create(64)
+            if not h:
+                raise _lib.ShgError("shg_exec_create failed: %s" % _lib.lib().shg_last_error_string().decode())
+            self._exec = h
+            R.exec = h
+        R.dtype = dtype_code
+        R.training = 1 if self.training else 0
+        R.stream = _stream()
+        side = self.wgrad_stream()
+        R.wgrad_stream = side.cuda_stream if side is not None else None
+        R.seed_state = self.seed_state.data_ptr()
+        return ctypes.addressof(R)
+
+    def __del__(self):
+        try:
+            if self._exec:
+                from . import _lib
+                _lib.lib().shg_exec_destroy(self._exec)
+                self._exec = None
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ arenas
     def adopt(self, model, active_names, groups=()):
@@ -203,16 +241,8 @@ class Engine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def begin_capture_pass(self, segment):
-        """graphed.GraphedSegment: while a segment's backward is captured, weight gradients and gradient-ready
-        notifications are recorded on it instead of being issued."""
-        self.capture_segment = segment
-
     def grad_written(self, p):
         self.grad_dirty = True
-        if self.capture_segment is not None:
-            self.capture_segment.record_written(p)
-            return
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(p._shg_off, p._shg_numel)
 

@@ -197,7 +197,7 @@ class BertCrossattLayer(nn.Module):
     def forward(self, input_tensor, ctx_tensor, ctx_att_mask=None):
         """Attention + output projection + residual LayerNorm as one fused sub-layer (ops.attn_sublayer)."""
         kind, mask = key_mask_2d(ctx_att_mask)
-        return ops.attn_sublayer(input_tensor, None, ctx_tensor, self._params(), kind, mask), None
+        return ops.attn_sublayer(input_tensor, ctx_tensor, self._params(), kind, mask), None
 
 
 class BertSelfattLayer(nn.Module):
@@ -220,7 +220,7 @@ class BertSelfattLayer(nn.Module):
     def forward(self, input_tensor, attention_mask):
         """Attention + output projection + residual LayerNorm as one fused sub-layer (ops.attn_sublayer)."""
         kind, mask = key_mask_2d(attention_mask)
-        return ops.attn_sublayer(input_tensor, None, None, self._params(), kind, mask), None
+        return ops.attn_sublayer(input_tensor, None, self._params(), kind, mask), None
 
 
 class BertIntermediate(nn.Module):

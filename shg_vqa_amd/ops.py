@@ -8,10 +8,12 @@ and lets the data-parallel reducer know exactly when a gradient slice is final.
 
 mc = AGQA/src/lxrt/modeling_capsbert.py of the reference.
 """
+import ctypes
 import os
 
 import torch
 
+from . import _lib
 from . import kernels as K
 from .engine import engine
 
@@ -163,9 +165,6 @@ def _wgrad(dy2, x2, weight, bias):
     (a captured hipGraph only runs coarse branches concurrently) and saves host time in eager mode."""
     E = engine()
     if weight._shg_grad is None:
-        return
-    if E.capture_segment is not None:          # backward of a graphed segment being captured: issued after each replay
-        E.capture_segment.record_wgrad(dy2, x2, weight, bias)
         return
     if E.wgrad_batch > 1 and E.wgrad_stream() is not None:
         E.deferred_wgrads.append((torch.cuda.current_stream(), dy2, x2, weight, bias))
@@ -786,28 +785,14 @@ def cross_attention_qkv(h, c, w_q, b_q, w_kv, b_kv, heads, mask_kind, mask, scal
 
 
 # ------------------------------------------------------------------------------------------------
-# Whole sub-layers as ONE autograd node each.  The forward / backward bodies are the same kernel
-# sequences as the small ops above, but (i) the residual gradient and the projection's input gradient
-# are summed by the dgrad GEMM's accumulate epilogue instead of an extra add kernel, (ii) the
-# LayerNorm's gamma / beta / bias column sums finish in one launch, (iii) Linear + GELU is one kernel,
-# and (iv) a sub-layer costs one autograd node instead of four (host time matters: a step is ~1 300
-# launches).
+# Whole sub-layers as ONE autograd node AND one C-ABI call each (csrc/executor.hip): shg_attn_sublayer_*,
+# shg_ffn_sublayer_*, shg_decoder_* enqueue the 6-16 kernels of a sub-layer (80 / 200 for a five-layer decoder) from C++,
+# so Python pays for ~100 calls per step instead of ~1 150 launches.  What the sequences do: (i) the residual gradient and
+# the projection's input gradient are summed by the dgrad GEMM's accumulate epilogue, (ii) a LayerNorm's gamma / beta /
+# bias column sums finish in one launch, (iii) Linear + GELU / ReLU (+ dropout) is one kernel forward and backward,
+# (iv) weight gradients go to the side stream behind an event (dW only feeds the optimiser).
 # ------------------------------------------------------------------------------------------------
-def _finish_ln_grads(dg, db, dbi, gamma, beta, bias):
-    E = engine()
-    parts, outs, ps = [], [], []
-    if gamma._shg_grad is not None:
-        parts += [dg, db]
-        outs += [gamma._shg_grad.view(-1), beta._shg_grad.view(-1)]
-        ps += [gamma, beta]
-    if dbi is not None and bias is not None and bias._shg_grad is not None:
-        parts.append(dbi)
-        outs.append(bias._shg_grad.view(-1))
-        ps.append(bias)
-    if parts:
-        K.colsum_finish_multi(parts, outs)
-        for q in ps:
-            E.grad_written(q)
+_ADDR = ctypes.addressof
 
 
 def _c2(t):
@@ -815,12 +800,129 @@ def _c2(t):
     return t2 if t2.is_contiguous() else t2.contiguous()
 
 
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _fill_linear(L, w, b):
+    E = engine()
+    L.w = _ptr(E.operand(w)) if w is not None else None
+    L.bias = _ptr(b._shg_store) if b is not None else None
+    L.gw = _ptr(w._shg_grad) if w is not None else None
+    L.gb = _ptr(b._shg_grad) if b is not None else None
+
+
+def _fill_norm(N, gamma, beta, eps):
+    N.gamma, N.beta = gamma._shg_store.data_ptr(), beta._shg_store.data_ptr()
+    N.g_gamma, N.g_beta = _ptr(gamma._shg_grad), _ptr(beta._shg_grad)
+    N.eps = eps
+
+
+def _trainable(*ps):
+    return [p for p in ps if p is not None and p._shg_grad is not None]
+
+
+def _note_grads(params):
+    """Tells the engine (and through it the data-parallel reducer) that these gradient slices are final for this
+    pass: every launch that writes them has been enqueued when the executor call returns."""
+    E = engine()
+    E.grad_dirty = True
+    if E.grad_ready_hook is not None:
+        for p in params:
+            E.grad_written(p)
+
+
+def _keep_for_side_stream(*tensors):
+    """Buffers the weight-gradient stream still reads after the call returned must not be recycled under it."""
+    side = engine().wgrad_stream()
+    if side is not None:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+
+
+def _bytes(n, dev):
+    return torch.empty(n, dtype=torch.uint8, device=dev)
+
+
 class FFNParams:
-    """Parameter handles + constants of a position-wise feed-forward sub-layer."""
+    """Parameter handles + constants of a position-wise feed-forward sub-layer (shg_ffn_sublayer_t)."""
 
     def __init__(self, w1, b1, w2, b2, gamma, beta, eps, act, p_inner, p_out):
         self.w1, self.b1, self.w2, self.b2, self.gamma, self.beta = w1, b1, w2, b2, gamma, beta
         self.eps, self.act, self.p_inner, self.p_out = eps, act, p_inner, p_out
+        self._c = None
+
+    def fill(self, L):
+        L.act, L.p_inner, L.p_out = self.act, self.p_inner, self.p_out
+        _fill_linear(L.l1, self.w1, self.b1)
+        _fill_linear(L.l2, self.w2, self.b2)
+        _fill_norm(L.ln, self.gamma, self.beta, self.eps)
+
+    def cstruct(self):
+        if self._c is None:
+            self._c = _lib.FfnSublayerT()
+            self.fill(self._c)
+            self.trainable = _trainable(self.w1, self.b1, self.w2, self.b2, self.gamma, self.beta)
+        return self._c
+
+
+_MODES = {"self": 0, "cross": 1, "dec_self": 2, "dec_cross": 3}
+
+
+class AttnParams:
+    """Parameter handles + constants of an attention sub-layer (shg_attn_sublayer_t).
+    mode: 'self'      q, k, v = W_in x                      (one GEMM, N = 3H; BertSelfattLayer mc:450-460)
+          'cross'     q = W_q x ; k, v = W_kv mem           (BertCrossattLayer mc:438-447)
+          'dec_self'  q, k = W_qk (x + pos) ; v = W_v x     (transformer.py:216-219)
+          'dec_cross' q = W_q (x + pos) ; k, v = W_kv mem   (transformer.py:222-226)
+    w_a / b_a: rows of the in-projection applied to the first source, w_b / b_b: rows applied to the second."""
+
+    def __init__(self, mode, w_a, b_a, w_b, b_b, w_o, b_o, gamma, beta, eps, heads, scale, p_attn, p_out):
+        self.mode, self.w_a, self.b_a, self.w_b, self.b_b, self.w_o, self.b_o = mode, w_a, b_a, w_b, b_b, w_o, b_o
+        self.gamma, self.beta, self.eps, self.heads, self.scale, self.p_attn, self.p_out = gamma, beta, eps, heads, scale, p_attn, p_out
+        self._c = None
+
+    def fill(self, L):
+        L.mode, L.heads, L.mask_kind, L.mask = _MODES[self.mode], self.heads, K.MASK_NONE, None
+        L.scale, L.p_attn, L.p_out = self.scale, self.p_attn, self.p_out
+        _fill_linear(L.a, self.w_a, self.b_a)
+        _fill_linear(L.b, self.w_b, self.b_b)
+        _fill_linear(L.o, self.w_o, self.b_o)
+        _fill_norm(L.ln, self.gamma, self.beta, self.eps)
+
+    def cstruct(self):
+        if self._c is None:
+            self._c = _lib.AttnSublayerT()
+            self.fill(self._c)
+            self.trainable = _trainable(self.w_a, self.b_a, self.w_b, self.b_b, self.w_o, self.b_o, self.gamma, self.beta)
+        return self._c
+
+
+class DecoderParams:
+    """The layer table of a TransformerDecoder (shg_decoder_layer_t[n]): per layer (AttnParams dec_self, AttnParams
+    dec_cross, FFNParams)."""
+
+    def __init__(self, layers):
+        self.layers = layers
+        self._c = None
+
+    def cstruct(self):
+        if self._c is None:
+            arr = (_lib.DecoderLayerT * len(self.layers))()
+            tr = []
+            for L, (ps, pc, pf) in zip(arr, self.layers):
+                ps.fill(L.self_attn)
+                pc.fill(L.cross_attn)
+                pf.fill(L.ffn)
+                tr += _trainable(ps.w_a, ps.b_a, ps.w_b, ps.b_b, ps.w_o, ps.b_o, ps.gamma, ps.beta,
+                                 pc.w_a, pc.b_a, pc.w_b, pc.b_b, pc.w_o, pc.b_o, pc.gamma, pc.beta,
+                                 pf.w1, pf.b1, pf.w2, pf.b2, pf.gamma, pf.beta)
+            self.trainable = tr
+            self.heads = self.layers[0][0].heads
+            self.ffn_dim = self.layers[0][2].w1.shape[0]
+            self._c = arr
+        return self._c
 
 
 class _FFNSublayer(torch.autograd.Function):
@@ -831,183 +933,146 @@ class _FFNSublayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, P):
         E = engine()
+        L = P.cstruct()
         x2 = _c2(x)
         rows, H = x2.shape
         F = P.w1.shape[0]
-        dev, dt = x2.device, x2.dtype
-        pi, seed_i, sid_i = _drop_args(P.p_inner)
-        po, seed_o, sid_o = _drop_args(P.p_out)
-        pre = torch.empty((rows, F), dtype=dt, device=dev)
-        h = torch.empty((rows, F), dtype=dt, device=dev)
-        # Linear + bias + activation (+ the decoder's inner dropout) in the GEMM epilogue
-        K.gemm_act(x2, E.operand(P.w1), h, P.b1._shg_store.view(-1), P.act, pre, pi, seed_i, sid_i)
-        fused = True
-        t = torch.empty((rows, H), dtype=dt, device=dev)
-        K.gemm(h, E.operand(P.w2), t, None, True, True)
-        y, z, mean, rstd = K.ln_fwd(t, P.b2._shg_store.view(-1), x2, P.gamma._shg_store, P.beta._shg_store, P.eps,
-                                    ACT_NONE, po, seed_o, sid_o, save_z=True)
-        ctx.save_for_backward(x2, pre, h, z, mean, rstd)
-        ctx.P, ctx.cfg = P, (fused, pi, seed_i, sid_i, po, seed_o, sid_o, x.shape)
+        dtc = K._dt(x2)
+        sid = E.take_stream_ids(2)
+        y = torch.empty_like(x2)
+        saved = _bytes(_lib.lib().shg_ffn_sublayer_saved_bytes(dtc, rows, H, F), x2.device)
+        _lib.call("shg_ffn_sublayer_fwd", _ADDR(L), E.run_addr(dtc), rows, H, F, x2.data_ptr(), y.data_ptr(), None, None,
+                  saved.data_ptr(), sid)
+        ctx.save_for_backward(x2, saved)
+        ctx.P, ctx.cfg = P, (sid, F, x.shape)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, pre, h, z, mean, rstd = ctx.saved_tensors
+        x2, saved = ctx.saved_tensors
         P = ctx.P
-        fused, pi, seed_i, sid_i, po, seed_o, sid_o, shape = ctx.cfg
+        sid, F, shape = ctx.cfg
         E = engine()
-        want_b2 = P.b2._shg_grad is not None
-        dt_, dres, dg, db, dbi = K.ln_bwd(_c2(dy), z, None, P.b2._shg_store.view(-1), P.gamma._shg_store, mean, rstd,
-                                          ACT_NONE, po, seed_o, sid_o, want_dx=True, want_dres=True, want_dbias=want_b2)
-        _finish_ln_grads(dg, db, dbi, P.gamma, P.beta, P.b2)
-        _wgrad(dt_, h, P.w2, None)
-        want_b1 = P.b1._shg_grad is not None
-        # activation (and inner dropout) backward + bias gradient in the dgrad GEMM's epilogue
-        dpre = torch.empty_like(h)
-        K.gemm_dact(dt_, E.operand(P.w2), dpre, pre, P.b1._shg_grad.view(-1) if want_b1 else None, P.act, pi, seed_i, sid_i)
-        if want_b1:
-            E.grad_written(P.b1)
-        _wgrad(dpre, x2, P.w1, None)
-        if not ctx.needs_input_grad[0]:
-            return None, None, None
-        K.gemm(dpre, E.operand(P.w1), dres, None, True, False, accumulate=True)      # dx = dres + dpre W1
-        return dres.view(shape), None, None
+        rows, H = x2.shape
+        dtc = K._dt(x2)
+        dy2 = _c2(dy)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        scratch = _bytes(_lib.lib().shg_ffn_sublayer_scratch_bytes(dtc, rows, H, F), x2.device)
+        _lib.call("shg_ffn_sublayer_bwd", _ADDR(P.cstruct()), E.run_addr(dtc), rows, H, F, x2.data_ptr(), saved.data_ptr(),
+                  dy2.data_ptr(), _ptr(dx), scratch.data_ptr(), sid)
+        _keep_for_side_stream(x2, saved, scratch)
+        _note_grads(P.trainable)
+        return (dx.view(shape) if dx is not None else None), None, None
 
 
 def ffn_sublayer(x, P):
     return _FFNSublayer.apply(x, _anchor(P.gamma), P)
 
 
-class AttnParams:
-    """Parameter handles + constants of an attention sub-layer.
-    mode: 'self'      q, k, v = W_in x                      (one GEMM, N = 3H; BertSelfattLayer mc:450-460)
-          'cross'     q = W_q x ; k, v = W_kv mem           (BertCrossattLayer mc:438-447)
-          'dec_self'  q, k = W_qk (x + pos) ; v = W_v x     (transformer.py:216-219)
-          'dec_cross' q = W_q (x + pos) ; k, v = W_kv mem   (transformer.py:222-226)
-    w_a / b_a: rows of the in-projection applied to the first source, w_b / b_b: rows applied to the second."""
-
-    def __init__(self, mode, w_a, b_a, w_b, b_b, w_o, b_o, gamma, beta, eps, heads, scale, p_attn, p_out):
-        self.mode, self.w_a, self.b_a, self.w_b, self.b_b, self.w_o, self.b_o = mode, w_a, b_a, w_b, b_b, w_o, b_o
-        self.gamma, self.beta, self.eps, self.heads, self.scale, self.p_attn, self.p_out = gamma, beta, eps, heads, scale, p_attn, p_out
-
-
 class _AttnSublayer(torch.autograd.Function):
-    """y = LayerNorm(x + drop_out(W_o attention(...) + b_o)), see AttnParams for the four projection layouts."""
+    """y = LayerNorm(x + drop_out(W_o attention(...) + b_o)) for the 'self' and 'cross' layouts of AttnParams
+    (the decoder layouts run inside shg_decoder_*, see decoder_stack)."""
 
     @staticmethod
-    def forward(ctx, x, pos, mem, anchor, P, mask_kind, mask):
+    def forward(ctx, x, mem, anchor, P, mask_kind, mask):
         E = engine()
-        mode = P.mode
+        L = P.cstruct()
+        if P.mode not in ("self", "cross"):
+            raise ValueError("attn_sublayer: decoder layouts go through decoder_stack")
         B, Sq, H = x.shape
         x2 = _c2(x)
-        dev, dt = x2.device, x2.dtype
-        pa, seed_a, sid_a = _drop_args(P.p_attn)
-        po, seed_o, sid_o = _drop_args(P.p_out)
-        xp2 = mem2 = None
-        if mode in ("dec_self", "dec_cross"):
-            xp2 = _c2(x + pos)
-        if mode in ("cross", "dec_cross"):
+        mem2 = None
+        Sk = Sq
+        if P.mode == "cross":
             Sk = mem.shape[1]
             mem2 = _c2(mem)
-        else:
-            Sk = Sq
-        wa, ba = E.operand(P.w_a), P.b_a._shg_store.view(-1)
-        if mode == "self":
-            qkv = torch.empty((B * Sq, 3 * H), dtype=dt, device=dev)
-            K.gemm(x2, wa, qkv, ba, True, True)
-            kvb = qkv
-            q3 = qkv.view(B, Sq, 3 * H)
-            q, k, v = q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:]
-        elif mode == "dec_self":
-            qkv = torch.empty((B * Sq, 3 * H), dtype=dt, device=dev)
-            K.gemm(xp2, wa, qkv[:, :2 * H], ba, True, True)
-            K.gemm(x2, E.operand(P.w_b), qkv[:, 2 * H:], P.b_b._shg_store.view(-1), True, True)
-            kvb = qkv
-            q3 = qkv.view(B, Sq, 3 * H)
-            q, k, v = q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:]
-        else:
-            qkv = torch.empty((B * Sq, H), dtype=dt, device=dev)
-            kvb = torch.empty((B * Sk, 2 * H), dtype=dt, device=dev)
-            K.gemm(xp2 if mode == "dec_cross" else x2, wa, qkv, ba, True, True)
-            K.gemm(mem2, E.operand(P.w_b), kvb, P.b_b._shg_store.view(-1), True, True)
-            q = qkv.view(B, Sq, H)
-            kv3 = kvb.view(B, Sk, 2 * H)
-            k, v = kv3[:, :, :H], kv3[:, :, H:]
-        o, lse = K.attention_fwd(q, k, v, P.heads, mask_kind, mask, P.scale, pa, seed_a, sid_a)
-        o2 = o.view(B * Sq, H)
-        t = torch.empty((B * Sq, H), dtype=dt, device=dev)
-        K.gemm(o2, E.operand(P.w_o), t, None, True, True)
-        y, z, mean, rstd = K.ln_fwd(t, P.b_o._shg_store.view(-1), x2, P.gamma._shg_store, P.beta._shg_store, P.eps,
-                                    ACT_NONE, po, seed_o, sid_o, save_z=True)
-        ctx.save_for_backward(x2, xp2, mem2, qkv, kvb if kvb is not qkv else None, o, lse, z, mean, rstd)
-        ctx.P = P
-        ctx.cfg = (mask_kind, mask, pa, seed_a, sid_a, po, seed_o, sid_o, (B, Sq, Sk, H))
+        dtc = K._dt(x2)
+        mask = K._mask_args(mask_kind, mask, B, Sq, Sk)
+        L.mask_kind, L.mask = mask_kind, _ptr(mask)
+        sid = E.take_stream_ids(2)
+        y = torch.empty_like(x2)
+        saved = _bytes(_lib.lib().shg_attn_sublayer_saved_bytes(L.mode, dtc, B, Sq, Sk, P.heads), x2.device)
+        _lib.call("shg_attn_sublayer_fwd", _ADDR(L), E.run_addr(dtc), B, Sq, Sk, x2.data_ptr(), None, _ptr(mem2), y.data_ptr(),
+                  None, None, saved.data_ptr(), sid)
+        ctx.save_for_backward(x2, mem2, saved)
+        ctx.P, ctx.cfg = P, (sid, mask_kind, mask, (B, Sq, Sk, H))
         return y.view(B, Sq, H)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, xp2, mem2, qkv, kvb, o, lse, z, mean, rstd = ctx.saved_tensors
+        x2, mem2, saved = ctx.saved_tensors
         P = ctx.P
-        mode = P.mode
-        mask_kind, mask, pa, seed_a, sid_a, po, seed_o, sid_o, (B, Sq, Sk, H) = ctx.cfg
+        sid, mask_kind, mask, (B, Sq, Sk, H) = ctx.cfg
         E = engine()
-        want_bo = P.b_o._shg_grad is not None
-        dt_, dres, dg, db, dbi = K.ln_bwd(_c2(dy), z, None, P.b_o._shg_store.view(-1), P.gamma._shg_store, mean, rstd,
-                                          ACT_NONE, po, seed_o, sid_o, want_dx=True, want_dres=True, want_dbias=want_bo)
-        _finish_ln_grads(dg, db, dbi, P.gamma, P.beta, P.b_o)
-        o2 = o.view(B * Sq, H)
-        _wgrad(dt_, o2, P.w_o, None)
-        d_o = torch.empty_like(o2)
-        K.gemm(dt_, E.operand(P.w_o), d_o, None, True, False)
-        d_o3 = d_o.view(B, Sq, H)
-        wa = E.operand(P.w_a)
-        need_x, need_pos, need_mem = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        dpos = dmem = None
-        if mode in ("self", "dec_self"):
-            q3 = qkv.view(B, Sq, 3 * H)
-            dqkv = torch.empty_like(qkv)
-            d3 = dqkv.view(B, Sq, 3 * H)
-            K.attention_bwd(q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:], o, d_o3, lse, d3[:, :, :H], d3[:, :, H:2 * H],
-                            d3[:, :, 2 * H:], P.heads, mask_kind, mask, P.scale, pa, seed_a, sid_a)
-            if mode == "self":
-                _wgrad(dqkv, x2, P.w_a, P.b_a)
-                if need_x:
-                    K.gemm(dqkv, wa, dres, None, True, False, accumulate=True)
-            else:
-                dqk, dv = dqkv[:, :2 * H], dqkv[:, 2 * H:]
-                _wgrad(dqk, xp2, P.w_a, P.b_a)
-                _wgrad(dv, x2, P.w_b, P.b_b)
-                if need_x or need_pos:
-                    dxp = torch.empty_like(x2)
-                    K.gemm(dqk, wa, dxp, None, True, False)
-                    if need_x:
-                        K.gemm(dv, E.operand(P.w_b), dres, None, True, False, accumulate=True)
-                        dres.add_(dxp)
-                    dpos = dxp.view(B, Sq, H) if need_pos else None
-        else:
-            kv3 = kvb.view(B, Sk, 2 * H)
-            dq = torch.empty_like(qkv)
-            dkv = torch.empty_like(kvb)
-            dkv3 = dkv.view(B, Sk, 2 * H)
-            K.attention_bwd(qkv.view(B, Sq, H), kv3[:, :, :H], kv3[:, :, H:], o, d_o3, lse, dq.view(B, Sq, H),
-                            dkv3[:, :, :H], dkv3[:, :, H:], P.heads, mask_kind, mask, P.scale, pa, seed_a, sid_a)
-            _wgrad(dq, xp2 if mode == "dec_cross" else x2, P.w_a, P.b_a)
-            _wgrad(dkv, mem2, P.w_b, P.b_b)
-            if mode == "cross":
-                if need_x:
-                    K.gemm(dq, wa, dres, None, True, False, accumulate=True)
-            elif need_x or need_pos:
-                dxp = torch.empty_like(x2)
-                K.gemm(dq, wa, dxp, None, True, False)
-                if need_x:
-                    dres.add_(dxp)
-                dpos = dxp.view(B, Sq, H) if need_pos else None
-            if need_mem:
-                dmem = torch.empty_like(mem2)
-                K.gemm(dkv, E.operand(P.w_b), dmem, None, True, False)
-                dmem = dmem.view(B, Sk, H)
-        return (dres.view(B, Sq, H) if need_x else None), dpos, dmem, None, None, None, None
+        L = P.cstruct()
+        L.mask_kind, L.mask = mask_kind, _ptr(mask)
+        dtc = K._dt(x2)
+        dy2 = _c2(dy)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dmem = torch.empty_like(mem2) if (mem2 is not None and ctx.needs_input_grad[1]) else None
+        scratch = _bytes(_lib.lib().shg_attn_sublayer_scratch_bytes(L.mode, dtc, B, Sq, Sk, P.heads), x2.device)
+        _lib.call("shg_attn_sublayer_bwd", _ADDR(L), E.run_addr(dtc), B, Sq, Sk, x2.data_ptr(), None, _ptr(mem2), saved.data_ptr(),
+                  dy2.data_ptr(), _ptr(dx), None, _ptr(dmem), 0, scratch.data_ptr(), sid)
+        _keep_for_side_stream(x2, mem2, saved, scratch)
+        _note_grads(P.trainable)
+        return (dx.view(B, Sq, H) if dx is not None else None), (dmem.view(B, Sk, H) if dmem is not None else None), None, None, None, None
 
 
-def attn_sublayer(x, pos, mem, P, mask_kind=K.MASK_NONE, mask=None):
-    return _AttnSublayer.apply(x, pos, mem, _anchor(P.gamma), P, mask_kind, mask)
+def attn_sublayer(x, mem, P, mask_kind=K.MASK_NONE, mask=None):
+    return _AttnSublayer.apply(x, mem, _anchor(P.gamma), P, mask_kind, mask)
+
+
+class _DecoderStack(torch.autograd.Function):
+    """All layers of a TransformerDecoder (transformer.py:86-124 over forward_post layers :212-233) as ONE node:
+    out = decoder(tgt, memory, query_pos, tgt_mask); tgt None = the zeros of agqa_model.py:234."""
+
+    @staticmethod
+    def forward(ctx, memory, qpos, tgt, anchor, D, tgt_mask):
+        E = engine()
+        arr = D.cstruct()
+        n = len(arr)
+        B, Q, H = qpos.shape
+        S = memory.shape[1]
+        mem2, qp2 = _c2(memory), _c2(qpos)
+        tgt2 = _c2(tgt) if tgt is not None else None
+        dtc = K._dt(mem2)
+        kind = K.MASK_FULL if tgt_mask is not None else K.MASK_NONE
+        tgt_mask = K._mask_args(kind, tgt_mask, B, Q, Q)
+        for L in arr:
+            L.self_attn.mask_kind, L.self_attn.mask = kind, _ptr(tgt_mask)
+        sid = E.take_stream_ids(6 * n)
+        out = torch.empty_like(qp2)
+        saved = _bytes(_lib.lib().shg_decoder_saved_bytes(n, dtc, B, Q, S, D.heads, D.ffn_dim), mem2.device)
+        _lib.call("shg_decoder_fwd", _ADDR(arr), n, E.run_addr(dtc), B, Q, S, D.ffn_dim, _ptr(tgt2), mem2.data_ptr(), qp2.data_ptr(),
+                  out.data_ptr(), saved.data_ptr(), sid)
+        ctx.save_for_backward(mem2, qp2, tgt2, saved)
+        ctx.D, ctx.cfg = D, (sid, kind, tgt_mask, (B, Q, S, H))
+        return out.view(B, Q, H)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        mem2, qp2, tgt2, saved = ctx.saved_tensors
+        D = ctx.D
+        sid, kind, tgt_mask, (B, Q, S, H) = ctx.cfg
+        E = engine()
+        arr = D.cstruct()
+        n = len(arr)
+        for L in arr:
+            L.self_attn.mask_kind, L.self_attn.mask = kind, _ptr(tgt_mask)
+        dtc = K._dt(mem2)
+        d2 = _c2(d_out)
+        dmem = torch.empty_like(mem2) if ctx.needs_input_grad[0] else None
+        dpos = torch.empty_like(qp2) if ctx.needs_input_grad[1] else None
+        dtgt = torch.empty_like(tgt2) if (tgt2 is not None and ctx.needs_input_grad[2]) else None
+        scratch = _bytes(_lib.lib().shg_decoder_scratch_bytes(n, dtc, B, Q, S, D.heads, D.ffn_dim), mem2.device)
+        _lib.call("shg_decoder_bwd", _ADDR(arr), n, E.run_addr(dtc), B, Q, S, D.ffn_dim, _ptr(tgt2), mem2.data_ptr(), qp2.data_ptr(),
+                  saved.data_ptr(), d2.data_ptr(), _ptr(dtgt), _ptr(dpos), _ptr(dmem), scratch.data_ptr(), sid)
+        _keep_for_side_stream(mem2, qp2, tgt2, saved, scratch)
+        _note_grads(D.trainable)
+        return ((dmem.view(B, S, H) if dmem is not None else None), (dpos.view(B, Q, H) if dpos is not None else None),
+                (dtgt.view(B, Q, H) if dtgt is not None else None), None, None, None)
+
+
+def decoder_stack(memory, query_pos, D, tgt_mask=None, tgt=None):
+    """memory [B,S,H], query_pos [B,Q,H], tgt [B,Q,H] or None (zeros); D: DecoderParams."""
+    return _DecoderStack.apply(memory, query_pos, tgt, _anchor(D.layers[0][2].gamma), D, tgt_mask)

@@ -84,13 +84,14 @@ class TransformerDecoderLayer(nn.Module):
                               self.norm3.weight, self.norm3.bias, self.norm3.eps, ops.ACT_RELU, p, self.dropout3.p))
         return self._sp
 
+    def _stack(self):
+        if getattr(self, "_dp", None) is None:
+            self._dp = ops.DecoderParams([self._params()])
+        return self._dp
+
     def forward_bf(self, tgt, memory, query_pos, tgt_mask):
-        """Batch-first forward_post (transformer.py:212-233): three fused sub-layers."""
-        p_self, p_cross, p_ffn = self._params()
-        kind = K.MASK_FULL if tgt_mask is not None else K.MASK_NONE
-        tgt = ops.attn_sublayer(tgt, query_pos, None, p_self, kind, tgt_mask)
-        tgt = ops.attn_sublayer(tgt, query_pos, memory, p_cross, K.MASK_NONE, None)
-        return ops.ffn_sublayer(tgt, p_ffn)
+        """Batch-first forward_post (transformer.py:212-233): the three fused sub-layers in one executor call."""
+        return ops.decoder_stack(memory, query_pos, self._stack(), tgt_mask, tgt)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):
@@ -123,11 +124,14 @@ class TransformerDecoder(nn.Module):
         self.norm = None
         self.return_intermediate = False
 
+    def _stack(self):
+        if getattr(self, "_dp", None) is None:
+            self._dp = ops.DecoderParams([layer._params() for layer in self.layers])
+        return self._dp
+
     def forward_bf(self, tgt, memory, query_pos, tgt_mask):
-        out = tgt
-        for layer in self.layers:
-            out = layer.forward_bf(out, memory, query_pos, tgt_mask)
-        return out
+        """All layers in ONE executor call (shg_decoder_fwd); tgt None = zeros (agqa_model.py:234)."""
+        return ops.decoder_stack(memory, query_pos, self._stack(), tgt_mask, tgt)
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):
