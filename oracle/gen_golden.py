@@ -166,6 +166,84 @@ def gen_q():
     print("q done", float(loss))
 
 
+def gen_vqa():
+    """--taskVQA (tasks/agqaVQA.py:237-258): video + question through the 5/2/5 stack, x-layers WITH gradients, pooler_dict.cross
+    and the answer head; BCE * n_answers; gradient norms of every parameter that trains."""
+    from . import ref_harness, shg_ref
+    argv = ["ref", "--llayers", "5", "--xlayers", "2", "--rlayers", "5", "--noCaps", "--crossAttnType", "cross",
+            "--batchSize", "2", "--taskVQA", "--fromScratch", "--backbone", "slow_r50", "--optim", "bert", "--lr", "1e-5"]
+    R = ref_harness.load(argv)
+    torch = R.torch
+    cfg = shg_ref.Cfg(task="vqa")
+    model = R.agqa_model.AGQAModel(cfg.num_answers)
+    model.eval()
+    _load_det_weights(torch, model)
+    batch = shg_ref.synthetic_batch(2, cfg, seed=4321)
+    logit, _ = model(batch["feat"], batch["pos"], input_ids=batch["input_ids"], input_masks=batch["input_mask"],
+                     segment_ids=batch["segment_ids"], rel_segment_ids=None, rel_tgt_mask=None, act_segment_ids=None,
+                     act_tgt_mask=None, hg_mask=None, rel_tgt_ids=None, act_tgt_ids=None)
+    loss = torch.nn.BCEWithLogitsLoss()(logit, batch["target"]) * logit.size(1)
+    model.zero_grad()
+    loss.backward()
+    gnames, gnorms, gheads = [], [], []
+    for n, prm in model.named_parameters():
+        if prm.grad is not None:
+            gnames.append(n)
+            gnorms.append(float(prm.grad.double().norm()))
+            gheads.append(_np(prm.grad.reshape(-1)[:4]).astype(np.float32))
+    total_norm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0))
+    np.savez_compressed(os.path.join(GOLD, "agqa_vqa_b2.npz"), batch_seed=np.int64(4321), batch_size=np.int64(2),
+                        logit=_np(logit), loss=_np(loss), grad_names=np.array(gnames), grad_norms=np.array(gnorms, np.float64),
+                        grad_heads=np.stack(gheads), grad_total_norm=np.float64(total_norm),
+                        param_names=np.array([n for n, _ in model.named_parameters()]))
+    print("vqa done: loss", float(loss), "grad norm", total_norm, "n grads", len(gnames))
+
+
+def gen_matcher_frames():
+    """Per-frame branch of the REAL reference matcher (lxrt/matcher.py:66-80, --LossHGPerFrame): raw logits -> indices for
+    >= 10 000 frames per head.  Logits are multiples of 1/64 stored as int16 (exact); every frame has 0..per labels, with
+    duplicated classes in a share of the frames (ties between identical cost columns)."""
+    from . import ref_harness
+    R = ref_harness.load()
+    torch = R.torch
+    m = R.matcher.HungarianMatcher(cost_class=1, loss_hg_per_frame=True, clip_len=16)
+    g = torch.Generator().manual_seed(20260101)
+    out = {}
+    for tag, (per, C) in {"rel": (8, 20), "act": (3, 12)}.items():
+        n_batches, B, T = 16, 40, 16                       # 16 x 40 x 16 = 10 240 frames
+        lg_all, tgt_all, len_all, q_all, t_all = [], [], [], [], []
+        for it in range(n_batches):
+            k = torch.randint(-256, 257, (B, T * per, C), generator=g)
+            if it % 4 == 3:                                  # coarse logits: exact ties between queries of a frame
+                k = (k // 64) * 64
+            logits = k.float() / 64.0
+            lens = torch.randint(0, per + 1, (B * T,), generator=g)
+            tgt = torch.zeros(B * T, per, dtype=torch.int64)
+            targets = []
+            for b in range(B):
+                labs = []
+                for f in range(T):
+                    n = int(lens[b * T + f])
+                    lab = torch.randint(1, C, (n,), generator=g)          # duplicates allowed
+                    tgt[b * T + f, :n] = lab
+                    labs.append(lab)
+                targets.append({"labels": labs})
+            idx = m({"pred_logits": logits}, targets)
+            oq = -torch.ones(B * T, per, dtype=torch.int64)
+            ot = -torch.ones(B * T, per, dtype=torch.int64)
+            for f, (i, j) in enumerate(idx):
+                oq[f, :len(i)], ot[f, :len(j)] = i, j
+            lg_all.append(k.to(torch.int16).view(B * T, per, C).numpy())
+            tgt_all.append(tgt.numpy().astype(np.int16))
+            len_all.append(lens.numpy().astype(np.int8))
+            q_all.append(oq.numpy().astype(np.int8))
+            t_all.append(ot.numpy().astype(np.int8))
+        out.update({tag + "_logits_x64": np.concatenate(lg_all), tag + "_tgt": np.concatenate(tgt_all),
+                    tag + "_len": np.concatenate(len_all), tag + "_q": np.concatenate(q_all), tag + "_t": np.concatenate(t_all)})
+    np.savez_compressed(os.path.join(GOLD, "matcher_frames.npz"), **out)
+    print("matcher_frames done:", {k: v.shape for k, v in out.items()})
+
+
 def gen_lsap():
     """Known answers + random problems solved by scipy.optimize.linear_sum_assignment."""
     from scipy.optimize import linear_sum_assignment
@@ -269,7 +347,7 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("hgqa", "star", "q", "lsap", "bertadam", "matcher_clip"):
+        for v in ("hgqa", "star", "q", "vqa", "lsap", "bertadam", "matcher_clip", "matcher_frames"):
             subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", v], env=env,
                                   cwd=os.path.dirname(HERE))
     elif what == "hgqa":
@@ -284,6 +362,10 @@ def main():
         gen_matcher_clip()
     elif what == "bertadam":
         gen_bertadam()
+    elif what == "vqa":
+        gen_vqa()
+    elif what == "matcher_frames":
+        gen_matcher_frames()
     else:
         raise SystemExit(f"unknown variant {what}")
 

@@ -176,13 +176,16 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
         assert rc in (0, 1)
         return tuple(out) if rc else None
 
-    for n_tiles, nk in [(222, 1440), (147, 540), (132, 180), (128, 64), (255, 97), (200, 333), (129, 1000), (248, 75)]:
+    # (the last two sit at the launcher's bound tiles * nk < 2^23, where the 32-bit plan arithmetic is largest: gemm.hip launch8)
+    for n_tiles, nk in [(222, 1440), (147, 540), (132, 180), (128, 64), (255, 97), (200, 333), (129, 1000), (248, 75),
+                        (128, 65535), (255, 32896)]:
+        assert n_tiles * nk < 2 ** 23
         r_min, r_max = n_tiles // 8, (n_tiles + 7) // 8
         den = 100 * (32 - r_max) + sigma * r_max
         per_wg = (sigma * r_max * nk + den - 1) // den         # head length on the fullest XCD
         if not (r_min >= 16 and r_max < 32 and per_wg >= 64 and nk - per_wg >= 8):
             continue                                            # (launch8 keeps the one-tile-per-workgroup launch there)
-        cover = [[0] * nk for _ in range(n_tiles)]
+        cover = [[] for _ in range(n_tiles)]                     # per tile: the [kb, kb + n) ranges handed out
         owners, expected_parts, published, work = {}, {}, {}, []
         first_head = {}
         for block in range(256):
@@ -193,8 +196,7 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
                     break
                 tile, kb, n, owner, slot, parts = d
                 assert 0 <= tile < n_tiles and n > 0 and 0 <= kb and kb + n <= nk
-                for k in range(kb, kb + n):
-                    cover[tile][k] += 1
+                cover[tile].append((kb, kb + n))
                 total += n
                 if owner:
                     assert tile not in owners and kb == 0 and seg == 0
@@ -206,7 +208,10 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
                     published[slot] = block
                     assert xcd not in first_head, "a tail workgroup after a head of its XCD"
             work.append(total)
-        assert all(c == 1 for row in cover for c in row), (n_tiles, nk)
+        for tile, ranges in enumerate(cover):                   # exact cover of [0, nk): sorted ranges abut
+            ranges.sort()
+            assert ranges[0][0] == 0 and ranges[-1][1] == nk, (n_tiles, nk, tile, ranges)
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), (n_tiles, nk, tile, ranges)
         assert sorted(owners) == list(range(n_tiles))
         for tile, parts in expected_parts.items():
             got = [s for s in (2 * tile, 2 * tile + 1) if s in published]

@@ -812,3 +812,128 @@ def test_gemm_small_problem_kernel(K):
     assert torch.equal(out.cpu(), a @ b.t())
     K.gemm(a.bfloat16().to(DEV), b.t().contiguous().bfloat16().to(DEV), out, None, True, False)
     assert torch.equal(out.cpu(), a @ b.t())
+
+
+# ------------------------------------------------------------------------------------------ per-frame matcher, 10k frames
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["rel", "act"])
+def test_hungarian_per_frame_bit_exact_vs_reference_matcher_golden_10k_frames(K, golden_dir, tag, dtype):
+    """matcher.py:66-80 (--LossHGPerFrame): 10 240 frames of raw logits per head; the golden indices come from the REAL
+    reference matcher (oracle/gen_golden.py matcher_frames).  The logits are multiples of 1/64 below 4 in magnitude, i.e. exact
+    in bf16 as well: both storage types must reproduce the reference's indices bit for bit."""
+    g = np.load(os.path.join(golden_dir, "matcher_frames.npz"))
+    k = g[tag + "_logits_x64"]
+    n, per, c = k.shape
+    assert n >= 10000
+    logits = (torch.from_numpy(k.astype(np.float32)) / 64.0).to(dtype)
+    assert torch.equal(logits.float() * 64.0, torch.from_numpy(k.astype(np.float32)))
+    tgt = torch.from_numpy(g[tag + "_tgt"].astype(np.int64)).to(DEV)
+    lens = torch.from_numpy(g[tag + "_len"].astype(np.int32)).to(DEV)
+    oq, ot, grid = K.hungarian_per_frame(logits.to(DEV), tgt, lens)
+    gq, gt = g[tag + "_q"].astype(np.int64), g[tag + "_t"].astype(np.int64)
+    bad = np.nonzero((oq.cpu().numpy() != gq).any(1) | (ot.cpu().numpy() != gt).any(1))[0]
+    assert bad.size == 0, (tag, dtype, bad[:10], oq[bad[:1]].cpu(), gq[bad[:1]])
+    exp = torch.zeros(n, per, dtype=torch.int64)
+    tg = torch.from_numpy(g[tag + "_tgt"].astype(np.int64))
+    for f in range(n):
+        m = int(g[tag + "_len"][f])
+        exp[f, torch.from_numpy(gq[f, :m])] = tg[f][torch.from_numpy(gt[f, :m])]
+    assert torch.equal(grid.cpu(), exp)
+
+
+# ------------------------------------------------------------------------------------------ convolutions at the benchmark's shape
+def _im2col(xp, T_out, H, W):
+    """Rows of the implicit GEMM: windows (5,3,3) of a zero-bordered channels-last tensor [B, T, H+2, W+2, C] -> [B*T_out*H*W, 45*C]."""
+    B, _, _, _, C = xp.shape
+    sB, sT, sH, sW, sC = xp.stride()
+    return xp.as_strided((B, T_out, H, W, 5, 3, 3, C), (sB, sT, sH, sW, sT, sH, sW, sC)).reshape(B * T_out * H * W, 45 * C)
+
+
+@pytest.mark.parametrize("name,Cin,T", [("conv1", 2048, 16), ("conv2", 768, 12)])
+def test_conv_forward_at_bench_shape_streamk_integer_exact_and_bf16_rows(K, name, Cin, T):
+    """The two convolutions exactly as bench.py runs them (B = 32: conv1 2048 -> 768 = 222 tiles x 1440 K-tiles, conv2 768 -> 768 =
+    147 tiles x 540 K-tiles, both on the stream-K split): (i) small-integer data, every output element equal to an fp32 im2col
+    GEMM; (ii) random bf16 data, 4 096 sampled output rows against the fp32 im2col GEMM of the same bf16 operands."""
+    from shg_vqa_amd import _lib
+    B, H, W, Cout = 32, 7, 7, 768
+    To = T - 4
+    gen = torch.Generator().manual_seed(11 + Cin)
+    before = int(_lib.lib().shg_gemm_streamk_launches())
+    # (i) integers
+    xi = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV)
+    xi[:, :, 1:-1, 1:-1] = torch.randint(-2, 3, (B, T, H, W, Cin), generator=gen).float().to(DEV)
+    wi = torch.randint(-1, 2, (Cout, 5, 3, 3, Cin), generator=gen).float().to(DEV)
+    bi = torch.randint(-3, 4, (Cout,), generator=gen).float().to(DEV)
+    ref = (_im2col(xi, To, H, W) @ wi.reshape(Cout, -1).t() + bi).bfloat16()
+    y = K.conv3d_k533_fwd(xi.bfloat16(), wi.bfloat16(), bi, act=0)
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(-1, Cout), ref), (y.view(-1, Cout).float() - ref.float()).abs().max()
+    del ref, xi, wi
+    # (ii) random data, sampled rows, GELU epilogue + pre-activation output as in the step
+    xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
+    xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
+    wr = (torch.randn(Cout, 5, 3, 3, Cin, generator=gen) / math.sqrt(45 * Cin)).to(DEV).bfloat16()
+    br = (torch.randn(Cout, generator=gen) * 0.1).to(DEV)
+    yg, pre = K.conv3d_k533_fwd(xr, wr, br, act=1, want_pre=True)
+    rows = torch.randperm(B * To * H * W, generator=gen)[:4096].to(DEV)
+    ref_pre = _im2col(xr.float(), To, H, W)[rows] @ wr.float().reshape(Cout, -1).t() + br
+    err_pre = (pre.view(-1, Cout)[rows].float() - ref_pre).abs().max().item()
+    err_act = (yg.view(-1, Cout)[rows].float() - F.gelu(ref_pre)).abs().max().item()
+    scale = ref_pre.abs().max().item()
+    print("%s fwd B=32: max |pre - ref| = %.3e, max |gelu - ref| = %.3e (|ref| max %.3f)" % (name, err_pre, err_act, scale))
+    assert err_pre <= 2 ** -8 * scale + 1e-3 and err_act <= 2 ** -8 * scale + 1e-3      # one bf16 rounding of an fp32 sum
+    assert int(_lib.lib().shg_gemm_streamk_launches()) == before + 2, "the stream-K path was not taken"
+
+
+@pytest.mark.parametrize("name,Cin,T", [("conv1", 2048, 16), ("conv2", 768, 12)])
+def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
+    """Weight gradients of both convolutions at B = 32 (conv1: 3 x 360 tiles of 256 x 256, K = 18 816 rows): integer data equal
+    to dY^T . im2col(X) in fp32; random bf16 data against the same fp32 product, 64 sampled output channels."""
+    B, H, W, Cout = 32, 7, 7, 768
+    To = T - 4
+    gen = torch.Generator().manual_seed(23 + Cin)
+    xi = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV)
+    xi[:, :, 1:-1, 1:-1] = torch.randint(-2, 3, (B, T, H, W, Cin), generator=gen).float().to(DEV)
+    dyi = torch.randint(-2, 3, (B, To, H, W, Cout), generator=gen).float().to(DEV)
+    ref = dyi.view(-1, Cout).t() @ _im2col(xi, To, H, W)
+    dw = torch.zeros(Cout, 5, 3, 3, Cin, device=DEV)
+    K.conv3d_k533_wgrad(xi.bfloat16(), dyi.bfloat16(), dw)
+    assert torch.equal(dw.view(Cout, -1), ref), (dw.view(Cout, -1) - ref).abs().max()
+    K.conv3d_k533_wgrad(xi.bfloat16(), dyi.bfloat16(), dw, accumulate=True)
+    assert torch.equal(dw.view(Cout, -1), 2 * ref)
+    del ref, xi, dyi
+    xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
+    xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
+    dyr = torch.randn(B, To, H, W, Cout, generator=gen).to(DEV).bfloat16()
+    K.conv3d_k533_wgrad(xr, dyr, dw)
+    ch = torch.randperm(Cout, generator=gen)[:64].to(DEV)
+    ref = dyr.view(-1, Cout)[:, ch].float().t() @ _im2col(xr.float(), To, H, W)
+    err = (dw.view(Cout, -1)[ch] - ref).abs().max().item()
+    print("%s wgrad B=32: max |dW - ref| = %.3e (|ref| max %.1f)" % (name, err, ref.abs().max().item()))
+    assert err <= 2e-4 * ref.abs().max().item() + 1e-3          # fp32 accumulation order only
+
+
+def test_conv2_dgrad_at_bench_shape_integer_exact_and_bf16(K):
+    """Input gradient of the second convolution at B = 32 (the only conv input gradient of the step; 147 tiles): integer data equal
+    to im2col(dY padded) x flipped weights in fp32; random bf16 data, 4 096 sampled rows."""
+    B, To, H, W, C = 32, 8, 7, 7, 768
+    gen = torch.Generator().manual_seed(37)
+
+    def flipped(w_cl):          # [(tap', co), ci] = W[co, 44 - tap', ci]
+        return w_cl.reshape(C, 45, C).flip(1).permute(1, 0, 2).reshape(45 * C, C)
+
+    dyi = torch.randint(-2, 3, (B, To, H, W, C), generator=gen).float().to(DEV)
+    wi = torch.randint(-1, 2, (C, 5, 3, 3, C), generator=gen).float().to(DEV)
+    dyp = F.pad(dyi, (0, 0, 1, 1, 1, 1, 4, 4))
+    ref = (_im2col(dyp, To + 4, H, W) @ flipped(wi)).bfloat16()
+    dx = K.conv3d_k533_dgrad(dyp.bfloat16(), wi.bfloat16())
+    assert torch.equal(dx.view(-1, C), ref), (dx.view(-1, C).float() - ref.float()).abs().max()
+    del ref
+    dyr = F.pad(torch.randn(B, To, H, W, C, generator=gen).to(DEV).bfloat16(), (0, 0, 1, 1, 1, 1, 4, 4))
+    wr = (torch.randn(C, 5, 3, 3, C, generator=gen) / math.sqrt(45 * C)).to(DEV).bfloat16()
+    dx = K.conv3d_k533_dgrad(dyr, wr)
+    rows = torch.randperm(B * (To + 4) * H * W, generator=gen)[:4096].to(DEV)
+    ref = _im2col(dyr.float(), To + 4, H, W)[rows] @ flipped(wr.float())
+    err = (dx.view(-1, C)[rows].float() - ref).abs().max().item()
+    print("conv2 dgrad B=32: max |dx - ref| = %.3e (|ref| max %.3f)" % (err, ref.abs().max().item()))
+    assert err <= 2 ** -8 * ref.abs().max().item() + 1e-3

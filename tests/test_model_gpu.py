@@ -122,26 +122,39 @@ def test_bf16_forward_is_close_to_reference_and_matching_is_self_consistent(gold
     engine().begin_step()
     engine().zero_grad()
     out = tr.forward_losses(b)
+    measured = {}
     for key, ref in (("logit", "logit"), ("hg_logit", "hg_logit"), ("rel_logit", "rel_preds"), ("act_logit", "act_preds")):
-        e = _rel_err(out[key], g[ref])
-        assert e < 6e-2, (key, e)
+        measured[key] = _rel_err(out[key], g[ref])
     exp = shg_ref.hungarian_per_frame(out["rel_logit"].float().cpu(), batch["rel_targets"], 16)
     q, t = out["rel_idx"]
     for n, (qi, ti) in enumerate(exp):
         k = len(qi)
         assert torch.equal(q[n, :k].cpu(), qi) and torch.equal(t[n, :k].cpu(), ti), n
-    assert abs(float(out["total"]) - float(g["total"])) < 0.05 * float(g["total"])
+    measured["total"] = abs(float(out["total"].detach()) - float(g["total"])) / float(g["total"])
     out["total"].backward()
     engine().join_side_streams()
     names = [str(x) for x in g["grad_names"]]
     params = dict(tr.model.named_parameters())
-    bad = []
+    rel = []
     for i, n in enumerate(names):
         ref = g["grad_norms"][i]
         got = params[n].grad.double().norm().item()
-        if abs(got - ref) > 0.1 * ref + 1e-6:
-            bad.append((n, got, ref))
-    assert len(bad) <= len(names) // 20, bad[:10]
+        rel.append((abs(got - ref) / (ref + 1e-6), n))
+    rel.sort()
+    measured["grad_norm_p50"], measured["grad_norm_p95"], measured["grad_norm_max"] = rel[len(rel) // 2][0], rel[int(len(rel) * 0.95)][0], rel[-1][0]
+    tot_ref = float(g["grad_total_norm"])
+    from shg_vqa_amd.optimization import clip_grad_norm_
+    measured["grad_total_norm"] = abs(clip_grad_norm_(tr.model.parameters(), 5.0).item() - tot_ref) / tot_ref
+    print("bf16 end-to-end errors vs the reference golden (B=2):", {k: float("%.3g" % v) for k, v in measured.items()},
+          "worst gradient:", rel[-1][1])
+    # bars = 2x what this prints on MI355X (round 2, gpurun_out/r2_t3.log: logit 1.20e-2, hg_logit 1.18e-2, rel_logit 1.40e-2,
+    # act_logit 1.53e-2 of the logit scale; total loss 1.6e-4; gradient norms p50 3.9e-4 / p95 1.7e-3; total gradient norm 2.4e-4;
+    # the worst single tensor is a key bias whose gradient is mathematically zero - softmax shift invariance - i.e. noise / 0)
+    for key, bar in BF16_BARS.items():
+        assert measured[key] <= bar, (key, measured[key], bar)
+
+
+BF16_BARS = dict(logit=2.5e-2, hg_logit=2.5e-2, rel_logit=3e-2, act_logit=3e-2, total=4e-4, grad_norm_p95=4e-3, grad_total_norm=6e-4)
 
 
 def test_train_steps_match_oracle_fp32():
@@ -231,6 +244,36 @@ def test_question_only_model_matches_reference_golden(golden_dir):
     assert _rel_err(out["logit"], g["logit"]) < 1e-3
     assert abs(float(out["total"]) - float(g["loss"])) < 1e-3 * float(g["loss"])
     assert set(n for n, _ in tr.model.named_parameters()) == set(str(x) for x in g["param_names"])
+
+
+def test_vqa_task_matches_reference_golden(golden_dir):
+    """BASELINE.json configs[1] against the REAL reference (agqaVQA.py:237-258; oracle/gen_golden.py vqa): answer logits <= 1e-3,
+    BCE * n_answers, and the norm of every gradient (201 tensors: here the x-layers and pooler_dict.cross train)."""
+    from oracle import shg_ref
+    g = np.load(os.path.join(golden_dir, "agqa_vqa_b2.npz"))
+    tr = _build_task("--taskVQA")
+    cfg = shg_ref.Cfg(task="vqa")
+    batch = shg_ref.synthetic_batch(int(g["batch_size"]), cfg, seed=int(g["batch_seed"]))
+    b = _device_batch(batch)
+    from shg_vqa_amd.engine import engine
+    from shg_vqa_amd.optimization import clip_grad_norm_
+    engine().begin_step()
+    tr.optim.zero_grad()
+    tr.model.eval()
+    out = tr.forward_losses(b)
+    assert _rel_err(out["logit"], g["logit"]) < 1e-3
+    assert abs(float(out["total"]) - float(g["loss"])) < 1e-3 * float(g["loss"])
+    out["total"].backward()
+    engine().join_side_streams()
+    names = [str(x) for x in g["grad_names"]]
+    params = dict(tr.model.named_parameters())
+    assert set(names) == tr.model.active_parameter_names()
+    for i, n in enumerate(names):
+        ref = g["grad_norms"][i]
+        got = params[n].grad.double().norm().item()
+        assert abs(got - ref) <= 5e-3 * ref + 1e-6, (n, got, ref)
+    tot = clip_grad_norm_(tr.model.parameters(), 5.0).item()
+    assert abs(tot - float(g["grad_total_norm"])) <= 2e-3 * float(g["grad_total_norm"])
 
 
 def test_vqa_task_train_step_matches_oracle():

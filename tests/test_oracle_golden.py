@@ -137,3 +137,46 @@ def test_oracle_per_clip_matching_equals_reference_matcher(golden_dir):
             for b, (qi, ti) in enumerate(idx):
                 n = int(lens[b])
                 assert np.array_equal(qi.numpy(), g[tag + "_q"][b, :n]) and np.array_equal(ti.numpy(), g[tag + "_t"][b, :n]), (tag, b)
+
+
+def test_vqa_task_matches_reference(golden_dir):
+    """--taskVQA (agqaVQA.py:237-258) through the REAL reference (golden) vs the oracle: answer logits, BCE * n_answers and the
+    gradient of every parameter that trains (here the x-layers and pooler_dict.cross do)."""
+    g = np.load(os.path.join(golden_dir, "agqa_vqa_b2.npz"))
+    cfg = shg_ref.Cfg(task="vqa")
+    p = shg_ref.det_params(cfg, requires_grad=True)
+    assert set(p) <= set(str(x) for x in g["param_names"])
+    batch = shg_ref.synthetic_batch(int(g["batch_size"]), cfg, seed=int(g["batch_seed"]))
+    out = shg_ref.agqa_forward(p, cfg, batch)
+    _close(out["logit"].detach(), g["logit"], 1e-4, 2e-5)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out["logit"], batch["target"]) * cfg.num_answers
+    _close(loss.detach(), g["loss"], 1e-5, 1e-5)
+    names = list(p)
+    grads = torch.autograd.grad(loss, [p[k] for k in names], allow_unused=True)
+    got = {k: gr for k, gr in zip(names, grads) if gr is not None}
+    ref_names = [str(x) for x in g["grad_names"]]
+    assert set(got) == set(ref_names)
+    for i, k in enumerate(ref_names):
+        n_ref = g["grad_norms"][i]
+        n_got = float(got[k].double().norm())
+        assert abs(n_got - n_ref) <= 2e-3 * max(n_ref, 1e-6) + 1e-7, (k, n_got, n_ref)
+    tot = float(torch.sqrt(sum((x.double() ** 2).sum() for x in got.values())))
+    assert abs(tot - float(g["grad_total_norm"])) <= 1e-3 * float(g["grad_total_norm"])
+
+
+def test_oracle_per_frame_matching_equals_reference_matcher_on_10k_frames(golden_dir):
+    """matcher.py:66-80 (--LossHGPerFrame) through the REAL reference on raw logits, 10 240 frames per head (golden), vs
+    the oracle's per-frame call: indices bit-exact."""
+    g = np.load(os.path.join(golden_dir, "matcher_frames.npz"))
+    for tag in ("rel", "act"):
+        k = g[tag + "_logits_x64"]
+        n, per, c = k.shape
+        assert n >= 10000
+        logits = torch.from_numpy(k.astype(np.float32) / 64.0).view(n // 16, 16 * per, c)
+        lens = g[tag + "_len"].astype(np.int64)
+        labels = [torch.from_numpy(g[tag + "_tgt"][f, :lens[f]].astype(np.int64)) for f in range(n)]
+        idx = shg_ref.hungarian_per_frame(logits, labels, clip_len=16)
+        for f, (qi, ti) in enumerate(idx):
+            m = int(lens[f])
+            assert np.array_equal(qi.numpy(), g[tag + "_q"][f, :m]) and np.array_equal(ti.numpy(), g[tag + "_t"][f, :m]), (tag, f)
+            assert (g[tag + "_q"][f, m:] == -1).all()
