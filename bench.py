@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and attention-stack measurements (N=1)")
     ap.add_argument("--overlap-update", action="store_true", help="overlap BertAdam's sweep with the next step's conv1")
     ap.add_argument("--force-ddp", action="store_true", help="use the gradient reducer / RCCL path even with one rank (testing)")
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce (N > 1)")
     ap.add_argument("--exec", dest="exec_mode", default="auto", choices=["auto", "graph", "eager"],
                     help="eager: launch every kernel from Python (weight gradients overlap the input-gradient chain on a "
                          "side stream); graph: replay the step from a captured hipGraph (no launch overhead, but the "
@@ -189,9 +190,9 @@ def main():
     model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=args)
     model.to_engine(cdt)
     E = engine()
-    reducer = GradReducer(E.grad_arena) if (world > 1 or a.force_ddp) else None
-    if reducer is not None and a.force_ddp:
-        reducer.world = 2 if world == 1 else reducer.world      # take the collective code path (a 1-rank all-reduce is the identity)
+    # --force-ddp with one rank: the collectives run anyway (a 1-rank all-reduce is the identity)
+    reducer = GradReducer(E.grad_arena, force_collectives=a.force_ddp,
+                          grad_dtype=torch.bfloat16 if a.grad_wire == "bf16" else None) if (world > 1 or a.force_ddp) else None
     trainer = AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=1), [None] * 1000, None), model=model, t_total=10000,
                    world=reducer)
     log("model in HBM arenas (%d params, %d with gradients); building batches" % (E.n_total, E.n_active))
@@ -229,6 +230,11 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    ranks_seen = 1
+    if dist.is_initialized():                              # proof that RCCL joined N ranks: every rank contributes its id
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ranks_seen = len({int(x.item()) for x in ids})
     log("timed region: %.3f s for %d steps" % (elapsed, a.steps))
 
     # dominant kernel: conv1 implicit GEMM, events recorded around its launch on its own stream
@@ -255,7 +261,8 @@ def main():
             "config": {"workload": "agqaHGQA.py --taskHGQA --LossHGPerFrame full SHG-VQA model, llayers/xlayers/rlayers 5/2/5, "
                                    "dlayers 5, slow_r50-shaped feats (B,2048,16,7,7), per-GPU batch %d, random --fromScratch init "
                                    "(BASELINE.json configs[2]; configs[4] at 8 GPUs)" % B,
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "execution": mode},
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "execution": mode, "ranks_seen": ranks_seen,
+                       "grad_wire": a.grad_wire if reducer is not None else None},
             "step_mfma_frac": round(qa / world * TRAIN_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"kernel": "gemm8_kernel<bf16, ConvRowSrc, PlainSrc, stream-K> (shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -8,7 +8,8 @@
  * Conventions
  *   - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer owned by the caller
  *     unless the comment says "host".  The library never allocates or frees device memory and holds
- *     no mutable global state besides the last error string.
+ *     no mutable global state besides the last error string, a launch counter for tests and the per-device "shared-memory limit
+ *     raised" bits of its kernels; workspaces and the executor's event ring are caller-owned handles.
  *   - Every function only enqueues work on `stream` (a hipStream_t passed as void*); it is safe to
  *     call during hipGraph stream capture.
  *   - Return value: 0 = ok, SHG_ERR_INVALID (<0) = bad argument (see shg_last_error_string()),
@@ -52,6 +53,11 @@ int64_t shg_gemm_streamk_launches(void);
  * partial-sum slot a tail publishes to, number of published parts the owner adds}.  Returns 1, or 0 when the workgroup has no
  * such segment (SHG_ERR_INVALID on bad arguments).  Pure host arithmetic, no GPU needed. */
 int shg_streamk_plan(int n_tiles, int nk, int block, int seg, int* out);
+/* Caller-owned workspace of that split (partial-sum slots + flags): shg_streamk_workspace_bytes() bytes of device memory,
+ * 16-byte aligned, initialised ONCE by shg_streamk_workspace_init (zeroes the flags on `stream`; launches leave them zero).
+ * One workspace serves the launches of one stream at a time; pass it to shg_conv3d_k533_fwd (NULL: no split). */
+int64_t shg_streamk_workspace_bytes(void);
+int shg_streamk_workspace_init(void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matcher, per-frame branch.
@@ -233,7 +239,7 @@ int64_t shg_conv3d_k533_workspace_bytes(int B, int T, int H, int W);
 int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int W, void* stream);
 int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T, int H,
                         int W, int Cin, int Cout, int act, int pad_out, void* y_pre, const void* workspace,
-                        void* stream);
+                        void* streamk_workspace, void* stream);
 int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                           int Cin, int Cout, int accumulate, const void* workspace, void* stream);
 int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,

@@ -43,7 +43,9 @@ _SIGNATURES = {
     "shg_gemm_act": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P, F, P, U, P], c_int),
     "shg_conv3d_k533_workspace_bytes": ([I, I, I, I], c_int64),
     "shg_conv3d_k533_prepare": ([P, I, I, I, I, P], c_int),
-    "shg_conv3d_k533_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P], c_int),
+    "shg_conv3d_k533_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P], c_int),
+    "shg_streamk_workspace_bytes": ([], c_int64),
+    "shg_streamk_workspace_init": ([P, P], c_int),
     "shg_conv3d_k533_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, P, P], c_int),
     "shg_conv3d_k533_dgrad": ([P, P, P, I, I, I, I, I, I, I, P, P], c_int),
     "shg_ncdhw_to_padded_cl": ([P, P, I, I, I, I, I, I, P], c_int),

@@ -245,15 +245,21 @@ class AGQA:
                 E.conv1_cache = self._conv1_bufs
             return self._step_body(self._static)
 
-        # The captured step keeps the weight-gradient stream but not the model's side-stream branches: ending a
-        # capture that holds their fork/re-enter/late-join pattern crashes inside the HIP runtime (ROCm 7.0), and
-        # the replayed graph serialises its branches anyway ("hipGraph mode").
-        branches, E.overlap_branches = E.overlap_branches, False
+        # Streams that join the capture, and where each re-joins the capturing (origin) stream O - DESIGN.md section 7 has the
+        # full sequence: S2 (language layers, deferred x-layers, pooler, answer head) -> O at ops.join_deferred_branch; S2 again
+        # (language <- hyper-graph half of the cross encoder) -> O at CrossLayer's side.join; S1 (action decoder) -> O at
+        # HGDecoder's branch.join; S1 again (heads, set losses) -> O at forward_losses' br_r.join; the backward nodes autograd
+        # replays on S1 / S2 and every weight gradient on W -> O at Engine.join_side_streams (clip_grad_norm_); nothing is
+        # issued on a side stream after that.  The ledger (Engine.unjoined) proves it for THIS body before the capture ends.
+        # ... with ONE branch stream: a capture that forks both branch streams ends cleanly, but its replay computes the
+        # relation head from a stale decoder output (deterministically; either stream alone replays bit-for-bit like eager
+        # steps, tools/graph_capture_ab.py) - so the language branch runs inline in the captured step.
+        mask, E.branch_mask = E.branch_mask, E.branch_mask & int(os.environ.get("SHG_CAPTURE_BRANCH_MASK", "2"))
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(2):                  # warm-up: caches (masks, gather tables), DDP write counts
+                for _ in range(2):                  # warm-up: caches (masks, gather tables, workspaces), DDP write counts
                     if w1 is not None:
                         _ops.conv1_forward(self._static["feat"], w1, b1, self._conv1_bufs)
                     body()
@@ -262,8 +268,13 @@ class AGQA:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._graph_out = body()
+                if E.unjoined:                      # would end in hipErrorStreamCaptureUnjoined (or worse) inside the runtime
+                    left = sorted(E.unjoined)
+                    E.join_side_streams()           # leave the capture in a state that can be ended, then report
+                    raise RuntimeError("AGQA.capture: side streams %s still hold work that the capturing stream never waited "
+                                       "for (a Branch / weight-gradient fork without its join)" % left)
         finally:
-            E.overlap_branches = branches
+            E.branch_mask = mask
             E.conv1_cache = None
         return self
 

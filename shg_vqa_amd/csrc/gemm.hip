@@ -21,8 +21,6 @@
 
 #include <algorithm>
 #include <atomic>
-#include <map>
-#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1131,7 +1129,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
             if (tid == 0) __hip_atomic_store(sk.flags + d.slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
-        // the tile's tail was computed by one or two tail workgroups of this XCD (lower block indices): add what they published
+        // the tile's tail was computed by one or two tail workgroups of this XCD (lower block indices): add what they published.
+        // ASSUMPTION this wait rests on: the hardware dispatches the workgroups of one launch in increasing block index, and a
+        // dispatched workgroup runs to completion without needing any later workgroup (tails never wait).  A head therefore only
+        // ever waits for workgroups that were dispatched before it; other kernels sharing the chip can delay the tails but not
+        // starve them.  tests/test_host_cpu.py checks on the plan that every publisher has a lower block index than its owner.
         for (int part = 0; part < d.parts; ++part) {
             const int sl = 2 * d.tile + part;
             if (tid == 0) {
@@ -1179,32 +1181,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
     }
 }
 
-// Partial-sum slots and flags of the stream-K launches, one set per HIP stream (launches on one stream are ordered, launches on
-// different streams may overlap).  Allocated on a stream's first use; never while that stream is being captured into a graph
-// (an allocation is illegal there): such a launch falls back to one tile per workgroup.
-static StreamK streamk_workspace(hipStream_t st) {
-    static std::mutex mu;
-    static std::map<hipStream_t, StreamK> sets;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = sets.find(st);
-    if (it != sets.end()) return it->second;
+// Partial-sum slots and flags of the stream-K launches live in a CALLER-OWNED workspace (shg_streamk_workspace_bytes /
+// shg_streamk_workspace_init; include/shg_vqa.h): 4 KiB of flags followed by STREAMK_SLOTS partial tiles.  One workspace serves
+// the launches of ONE stream at a time (launches on a stream are ordered; two streams could overlap and need one each).
+constexpr size_t STREAMK_FLAG_BYTES = 4096;
+static StreamK streamk_view(void* ws) {
     StreamK sk{nullptr, nullptr, 0, 100};
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return sk;                                   // (not remembered: the stream may allocate later)
+    if (ws) {
+        sk.flags = reinterpret_cast<int*>(ws);
+        sk.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + STREAMK_FLAG_BYTES);
     }
-    const size_t flag_bytes = 4096, bytes = STREAMK_SLOTS * STREAMK_SLOT * sizeof(float) + flag_bytes;
-    char* base = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&base), bytes) == hipSuccess && hipMemset(base, 0, flag_bytes) == hipSuccess &&
-        hipDeviceSynchronize() == hipSuccess) {
-        sk.flags = reinterpret_cast<int*>(base);
-        sk.ws = reinterpret_cast<float*>(base + flag_bytes);
-    } else {
-        (void)hipGetLastError();
-    }
-    sets[st] = sk;
     return sk;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (instantiation, device)
+static bool lds_raised(std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    const uint64_t bit = (uint64_t)1 << dev;
+    if (mask.load(std::memory_order_relaxed) & bit) return true;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return false;
 }
 
 static std::atomic<int64_t> g_streamk_launches{0};
@@ -1216,30 +1213,30 @@ static int streamk_sigma() {
 
 template <typename TC, typename SrcA, typename SrcB, int ALLOW_SK = 0>     // ALLOW_SK: bit of SHG_STREAMK that enables the split
 static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, hipStream_t st, const char* what,
-                   int split = 1) {
+                   int split = 1, void* streamk_ws = nullptr) {
     const int64_t gm = (M + 255) / 256, gn = (N + 255) / 256, tiles = gm * gn, nk = K / BK;
     if (tiles > 0x7fffffff) return fail_arg("gemm: grid too large");
     const size_t lds = std::max<size_t>(2 * 8 * Tile64<bf16_t>::BYTES, (size_t)8 * 64 * STG_LD * 4);
     if constexpr (ALLOW_SK) {
         // stream-K when the even split is worth more than its segment overhead: rounds of whole tiles against the busiest
         // XCD's share of K-tiles (32 workgroups each), and ranges long enough to hide a second pipeline fill.
-        // SHG_STREAMK: bit 0 conv forward (default on: conv2's 147 tiles 777 -> 620 us, conv1 inside the step 2.18 -> 2.04 ms),
+        // SHG_STREAMK: bit 0 conv forward (default on: conv2's 147 tiles 777 -> 620 us, conv1 inside the step 2.18 -> 2.04 ms);
+        // the split needs the caller's workspace (streamk_ws), else the launch stays one tile per workgroup.  Measured and not
+        // instantiated any more:
         // bit 1 conv input gradient (measured slower: 791 -> 859 us), bit 2 conv weight gradient (2x slower: the gathered-B
         // variant of the segment loop does not keep its registers)
         static const int streamk = []() { const char* e = getenv("SHG_STREAMK"); return e ? atoi(e) : 1; }();
         // (every XCD needs 16 <= R < 32 tiles: heads and tails both exist and a tile's tail is cut at most once)
         const int64_t r_min = tiles / 8, r_max = (tiles + 7) / 8, sg = streamk_sigma();
         const int64_t per_wg = (sg * r_max * nk + 100 * (32 - r_max) + sg * r_max - 1) / (100 * (32 - r_max) + sg * r_max);   // head length
-        if ((streamk & ALLOW_SK) && split == 1 && !ep.atomic && r_min >= 16 && r_max < 32 && per_wg >= 64 && nk - per_wg >= 8 &&
-            tiles * nk < ((int64_t)1 << 23)) {             // (32-bit plan arithmetic: sigma R nk stays below 2^31)
-            StreamK sk = streamk_workspace(st);
-            if (sk.ws) {
+        if ((streamk & ALLOW_SK) && streamk_ws && split == 1 && !ep.atomic && r_min >= 16 && r_max < 32 && per_wg >= 64 &&
+            nk - per_wg >= 8 && tiles * nk < ((int64_t)1 << 23)) {             // (32-bit plan arithmetic: sigma R nk stays below 2^31)
+            StreamK sk = streamk_view(streamk_ws);
+            {
                 auto kern = gemm8_kernel<TC, SrcA, SrcB, true>;
-                static bool raised_sk = false;               // per instantiation
-                if (!raised_sk) {
+                static std::atomic<uint64_t> raised_sk{0};   // per instantiation, one bit per device
+                if (!lds_raised(raised_sk))
                     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    raised_sk = true;
-                }
                 sk.n_tiles = (int)tiles;
                 sk.sigma = (int)sg;
                 g_streamk_launches.fetch_add(1, std::memory_order_relaxed);
@@ -1249,11 +1246,9 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
         }
     }
     auto kern = gemm8_kernel<TC, SrcA, SrcB, false>;
-    static bool raised = false;                      // per instantiation
-    if (!raised) {
+    static std::atomic<uint64_t> raised{0};          // per instantiation, one bit per device
+    if (!lds_raised(raised))
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        raised = true;
-    }
     if (split > 1) ep.atomic = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, split), dim3(512), lds, st, sa, sb, ep, M, N, K,
                        tile_order(gm, gn), StreamK{nullptr, nullptr, 0, 100});
@@ -1292,11 +1287,9 @@ static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, i
     }
     auto kern = gemm_kernel<T, TC, SrcA, SrcB, TM, TN, WM, WN>;
     if (lds > 64 * 1024) {
-        static bool raised = false;          // per instantiation
-        if (!raised) {
+        static std::atomic<uint64_t> raised{0};      // per instantiation, one bit per device
+        if (!lds_raised(raised))
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            raised = true;
-        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn), split), dim3(NTHR), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn));
     return check_launch(what);
@@ -1508,10 +1501,22 @@ extern "C" int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int
     return check_launch("conv3d_prepare");
 }
 
+extern "C" int64_t shg_streamk_workspace_bytes(void) {
+    return (int64_t)(STREAMK_FLAG_BYTES + STREAMK_SLOTS * STREAMK_SLOT * sizeof(float));
+}
+
+extern "C" int shg_streamk_workspace_init(void* ws, void* stream) {
+    if (!ws || !al16(ws)) return fail_arg("streamk_workspace_init: workspace missing or unaligned");
+    hipError_t e = hipMemsetAsync(ws, 0, STREAMK_FLAG_BYTES, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
                                    int H, int W, int Cin, int Cout, int act, int pad_out, void* y_pre,
-                                   const void* workspace, void* stream) {
+                                   const void* workspace, void* streamk_ws, void* stream) {
     if (!x || !w || !y) return fail_arg("conv3d_fwd: null pointer");
+    if (streamk_ws && !al16(streamk_ws)) return fail_arg("conv3d_fwd: streamk workspace must be 16-byte aligned");
     if (y_pre && !al16(y_pre)) return fail_arg("conv3d_fwd: y_pre must be 16-byte aligned");
     if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
     if (!al16(x) || !al16(w) || !al16(y)) return fail_arg("conv3d_fwd: pointers must be 16-byte aligned");
@@ -1530,7 +1535,7 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre, 0};
     if (use_gemm8(M, N, K, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2, N * K * 2)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
-        return launch8<bf16_t, decltype(sa), decltype(sb), 1>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd");
+        return launch8<bf16_t, decltype(sa), decltype(sb), 1>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", 1, streamk_ws);
     }
     if (use_large(1, M, N, K)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
@@ -1559,7 +1564,7 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
     PlainSrc<bf16_t, false> sa{(const bf16_t*)dy, Cout, 0, Cout, Mo};
     if (use_gemm8(Cout, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
-        return launch8<float, decltype(sa), decltype(sb), 4>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+        return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
     }
     if (use_large(1, Cout, Ncols, Mo)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
@@ -1591,7 +1596,7 @@ extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void*
     Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
     if (Cout % 64 == 0 && use_gemm8(M, N, K, (int64_t)B * Tp * (H + 2) * (W + 2) * Cout * 2, (int64_t)64 * 45 * Cin * 2)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
-        return launch8<bf16_t, decltype(sa), decltype(sb), 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
+        return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
     }
     if (use_large(1, M, N, K)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};

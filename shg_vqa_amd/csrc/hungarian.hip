@@ -111,7 +111,9 @@ __global__ __launch_bounds__(64) void hungarian_per_frame_kernel(
             for (int c = lane; c < C; c += 64) sum += expf(to_f32(row[c]) - mx);
             sum = wave_sum(sum);
             if (lane < n) {
-                const int64_t cls = tgt[(int64_t)f * R + lane];
+                // (a class id outside [0, C) is a caller error - the reference's out_prob[:, tgt_ids] raises IndexError,
+                // matcher.py:74; the host wrappers check it - here it is clamped so that the read stays inside the row)
+                const int64_t cls = min(max(tgt[(int64_t)f * R + lane], (int64_t)0), (int64_t)C - 1);
                 const float p = expf(to_f32(row[cls]) - mx) / sum;
                 const double cst = (double)(-p);
                 // n == R: solve with rows = queries; n < R: solve the transpose (rows = targets)
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64) void hungarian_wave_kernel(
         for (int c = lane; c < C; c += 64) sum += expf(to_f32(row[c]) - mx);
         sum = wave_sum(sum);
         for (int t = lane; t < n; t += 64) {
-            const int64_t cls = tgt[(int64_t)f * R + t];
+            const int64_t cls = min(max(tgt[(int64_t)f * R + t], (int64_t)0), (int64_t)C - 1);      // (see above: kept inside the row)
             const float pr = expf(to_f32(row[cls]) - mx) / sum;
             if (transposed) s.cost[(size_t)t * R + q] = -pr; else s.cost[(size_t)q * R + t] = -pr;
         }

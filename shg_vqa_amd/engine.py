@@ -60,12 +60,15 @@ class Engine:
         self.deferred_wgrads = []
         self.overlap_branches = os.environ.get("SHG_OVERLAP_BRANCHES", "1") != "0"   # independent sub-graphs (action decoder, language layers) on side streams
         self._aux_streams = {}
+        # bit i: branch stream i may be used (measurement switch; AGQA.capture keeps only stream 1 while capturing)
+        self.branch_mask = int(os.environ.get("SHG_BRANCH_MASK", "255"))
         # --taskHGQA: the cross-modality x-layers, their pooler and the answer head only produce `logit`, which
         # the HGQA loss never reads (agqaHGQA.py:344-345 uses hg_logit).  They stay on the language branch's
         # stream, off the critical path, until AGQAModel.forward joins it (ops.Branch.reenter / join)
         self.defer_x_layers = False
         self.deferred_branch = None
         self.grad_dirty = False           # gradients written since the arena was last zeroed
+        self.unjoined = set()             # side streams that received work since the last join_side_streams() (fork / join ledger)
         self._exec = None                 # shg_exec_t* of the sub-layer executor (event ring for the weight-gradient stream)
         self._run = None                  # persistent shg_run_t handed to every executor call
         self.params_ready_event = None
@@ -118,8 +121,15 @@ class Engine:
         R.stream = _stream()
         side = self.wgrad_stream()
         R.wgrad_stream = side.cuda_stream if side is not None else None
+        if side is not None:
+            self.unjoined.add(side.cuda_stream)
         R.seed_state = self.seed_state.data_ptr()
         return ctypes.addressof(R)
+
+    def note_fork(self, stream):
+        """Fork / join ledger: `stream` has received work that the step's origin stream has not waited for yet.
+        join_side_streams() clears it; AGQA.capture() refuses to end a capture while it is non-empty."""
+        self.unjoined.add(stream.cuda_stream)
 
     def __del__(self):
         try:
@@ -208,13 +218,15 @@ class Engine:
         """Side stream for an independent branch of the model (None: run it inline)."""
         if not self.overlap_branches or self.device.type != "cuda" or i < 0:
             return None
+        if not (self.branch_mask >> i) & 1:
+            return None
         if i not in self._aux_streams:
             self._aux_streams[i] = torch.cuda.Stream(device=self.device)
         return self._aux_streams[i]
 
     def side_streams(self):
-        aux = list(self._aux_streams.values()) if self.overlap_branches else []    # (idle while branches run inline)
-        return [s for s in (self._wgrad_stream,) if s is not None] + aux
+        """Every side stream this engine has created (idle ones cost one event each to wait for)."""
+        return [s for s in (self._wgrad_stream,) if s is not None] + list(self._aux_streams.values())
 
     def join_side_streams(self):
         """Makes the current stream wait for all weight-gradient work issued so far."""
@@ -222,8 +234,11 @@ class Engine:
             from . import ops
             ops.flush_wgrads()
         cur = torch.cuda.current_stream()
+        joined = set()
         for s in self.side_streams():
             cur.wait_stream(s)
+            joined.add(s.cuda_stream)
+        self.unjoined -= joined
 
     def zero_grad(self):
         """The optimiser pass leaves the gradient arena zeroed (BertAdam.step): the sweep is only needed when

@@ -359,6 +359,25 @@ def conv_workspace(B, T, H, W, device):
     return ws
 
 
+_streamk_ws = {}
+
+
+def streamk_workspace(device):
+    """Partial-sum slots + flags of the stream-K conv forward for torch's CURRENT stream on `device` (one workspace per
+    (device, stream): launches on one stream are ordered, two streams may overlap).  Allocated and zeroed on first use;
+    None while the stream is being captured into a graph and has none yet (an allocation is illegal there)."""
+    st = _stream()
+    key = (torch.device(device).index or 0, st)
+    ws = _streamk_ws.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ws = torch.empty(_lib.lib().shg_streamk_workspace_bytes(), dtype=torch.uint8, device=device)
+        _lib.call("shg_streamk_workspace_init", ws.data_ptr(), st)
+        _streamk_ws[key] = ws
+    return ws
+
+
 def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None):
     """x_cl [B,T,H+2,W+2,Cin] (zero border); w_cl [Cout,5,3,3,Cin]; -> y [B,T-4,H,W,Cout]
     (or written into the interior of a zero-bordered [B,T-4,H+2,W+2,Cout] buffer when pad_out)."""
@@ -378,8 +397,9 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, wan
     if want_pre:
         pre = pre_out if pre_out is not None else torch.empty((B, T - 4, H, W, cout), dtype=x_cl.dtype, device=x_cl.device)
         _need(pre.is_contiguous() and pre.dtype == x_cl.dtype and pre.numel() == B * (T - 4) * H * W * cout, "bad pre_out")
+    sk = streamk_workspace(x_cl.device) if x_cl.dtype == torch.bfloat16 else None
     _lib.call("shg_conv3d_k533_fwd", x_cl.data_ptr(), w_cl.data_ptr(), _p(bias), out.data_ptr(), _dt(x_cl), B, T, H, W, cin,
-              cout, act, 1 if pad_out else 0, _p(pre), ws.data_ptr(), _stream())
+              cout, act, 1 if pad_out else 0, _p(pre), ws.data_ptr(), _p(sk), _stream())
     return (out, pre) if want_pre else out
 
 

@@ -8,7 +8,10 @@ from . import kernels as K
 
 
 def pad_frame_targets(targets, per_frame, device):
-    """list (B) of {"labels": [clip_len tensors]} -> (tgt [B*clip_len, per_frame] int64, len int32)."""
+    """list (B) of {"labels": [clip_len tensors]} -> (tgt [B*clip_len, per_frame] int64, len int32).
+    A frame with MORE labels than query slots raises: SciPy would solve that rectangular problem (every query matched,
+    surplus labels dropped), but the dataset never produces it (agqa_data.py truncates to num_rel / num_act per frame) and the
+    per-frame kernel keeps one lane per label of at most per_frame labels."""
     flat = [t for d in targets for t in d["labels"]]
     tgt = torch.zeros((len(flat), per_frame), dtype=torch.int64)
     lens = torch.zeros(len(flat), dtype=torch.int32)
@@ -69,6 +72,10 @@ class HungarianMatcher(nn.Module):
         else:
             per = logits.shape[1] // self.clip_len
             tgt, lens = pad_frame_targets(targets, per, logits.device)
+        # the reference's out_prob[:, tgt_ids] (matcher.py:74, :91) raises IndexError for a class id outside the logits;
+        # this entry point is off the hot path, so the check may synchronise (the kernel itself clamps the read)
+        if tgt.numel() and (int(tgt.max()) >= logits.shape[-1] or int(tgt.min()) < 0):
+            raise IndexError("target class id outside [0, %d)" % logits.shape[-1])
         oq, ot, _ = self.match_padded(logits, tgt, lens)
         oq, ot, lens = oq.cpu(), ot.cpu(), lens.cpu()
         return [(oq[i, : int(lens[i])].clone(), ot[i, : int(lens[i])].clone()) for i in range(oq.shape[0])]

@@ -84,6 +84,11 @@ class Branch:
 
     def __init__(self, index, *inputs, wait=True):
         self.side = engine().aux_stream(index)
+        # a branch asked for from INSIDE the same side stream (the cross layers' language <- vision half when the x-layers
+        # already run deferred on that stream) runs inline: forking a stream from itself is an event the stream records and
+        # then waits for - harmless eagerly, but a self-edge in a stream capture
+        if self.side is not None and self.side == torch.cuda.current_stream():
+            self.side = None
         self.main = torch.cuda.current_stream() if self.side is not None else None
         self.inputs = inputs
         self.wait = wait          # False: everything the block reads was produced on the side stream itself (or long ago)
@@ -97,6 +102,7 @@ class Branch:
             for t in self.inputs:
                 if t is not None:
                     t.record_stream(self.side)
+            engine().note_fork(self.side)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
         return self
@@ -143,6 +149,7 @@ class _WgradStream:
         if self.side is None:
             return self
         self.side.wait_stream(torch.cuda.current_stream())
+        self.E.note_fork(self.side)
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self
@@ -188,6 +195,7 @@ def flush_wgrads():
     if not q:
         return
     side = E.wgrad_stream()
+    E.note_fork(side)
     seen = []
     for st, *_ in q:
         if all(st != o for o in seen):

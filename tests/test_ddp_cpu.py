@@ -89,3 +89,37 @@ def test_single_process_reducer_is_a_no_op():
     assert torch.equal(arena, torch.arange(10.0))
     s = torch.tensor([1.0, 2.0, 0.0, 0.0])
     assert r.global_loss_sums(s) is s
+
+
+def test_bucket_bounds_follow_parameter_bounds():
+    """A large tensor gets buckets of its own (conv1's 283 MB weight gradient must not share a bucket with the embeddings,
+    which are written at the other end of backward); small tensors are packed up to the bucket size; the cover is exact."""
+    from shg_vqa_amd.ddp import param_aligned_bounds
+    spans = [(0, 100), (104, 50), (160, 1000), (1160, 8), (1168, 300), (1472, 40)]      # (offset, numel), 8-aligned offsets
+    n = 1512
+    b = param_aligned_bounds(n, 256, spans)
+    assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    big = [x for x in b if x[0] >= 160 and x[1] <= 1160]
+    assert big[0][0] == 160 and big[-1][1] == 1160 and len(big) == 4 and all(e - s <= 256 for s, e in big)
+    assert (0, 160) in b                                   # the two small tensors in front of it
+    assert (1160, 1468) in b and b[-1] == (1468, n)        # the 300-element tensor closes a bucket at its own end
+    assert param_aligned_bounds(1000, 256, None) == [(0, 256), (256, 512), (512, 768), (768, 1000)]
+
+
+def test_reducer_raises_when_a_step_writes_differently_from_the_learning_step():
+    from shg_vqa_amd.ddp import GradReducer
+    arena = torch.zeros(64)
+    r = GradReducer(arena, bucket_bytes=4 * 32)
+    for _ in range(2):
+        r.begin_step()
+        r.on_grad(0, 32)
+        r.on_grad(32, 32)
+        r.finish()
+    r.begin_step()
+    r.on_grad(0, 32)
+    with pytest.raises(RuntimeError, match="written"):
+        r.on_grad(0, 32)                                   # a second write the learning step did not have
+    r.begin_step()
+    r.on_grad(0, 32)
+    with pytest.raises(RuntimeError, match="written"):
+        r.finish()                                         # bucket 1 was never written

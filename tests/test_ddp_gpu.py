@@ -112,3 +112,81 @@ def test_two_ranks_match_single_process_on_the_global_batch():
     for p in procs:
         p.join(timeout=120)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_bucket_collective_waits_for_the_main_stream_when_the_last_write_came_from_a_branch_stream(monkeypatch):
+    """A bucket that mixes parameters written on the main stream with parameters written on a branch stream (autograd runs a
+    backward node on the stream of its forward): when the LAST write is reported from the branch stream, the collective must
+    still be ordered behind the earlier main-stream write.  The collective is replaced by an in-place doubling (what a two-rank
+    sum of equal gradients does), the main-stream write is delayed by a long spin kernel: without the ordering the doubling
+    would run first and the late write would land un-doubled on top."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from shg_vqa_amd import ddp
+    from shg_vqa_amd.engine import reset_engine
+    reset_engine(compute_dtype=torch.float32)
+    n = 1 << 16
+    arena = torch.zeros(n, device="cuda")
+    red = ddp.GradReducer(arena, bucket_bytes=4 * n, force_collectives=True, param_spans=[(0, n // 2), (n // 2, n // 2)])
+    assert len(red.bounds) == 1
+    monkeypatch.setattr(ddp.dist, "all_reduce", lambda view, op=None, async_op=False: view.mul_(2))
+    aux = torch.cuda.Stream()
+    for step in range(3):
+        arena.zero_()
+        torch.cuda.synchronize()
+        red.begin_step()
+        if step:
+            torch.cuda._sleep(200_000_000)                  # ~0.1 s on the main stream before its write
+        arena[: n // 2].add_(1.0)
+        red.on_grad(0, n // 2)
+        with torch.cuda.stream(aux):                        # the branch stream: independent of the main stream's work
+            arena[n // 2:].add_(3.0)
+            red.on_grad(n // 2, n // 2)                     # last expected write -> launches the bucket from here
+        red.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(arena[: n // 2], torch.full((n // 2,), 2.0, device="cuda")), (step, arena[:4])
+        assert torch.equal(arena[n // 2:], torch.full((n // 2,), 6.0, device="cuda")), (step, arena[-4:])
+
+
+def _nccl_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from shg_vqa_amd.ddp import GradReducer
+        from shg_vqa_amd.engine import engine
+        ref_tr = _build(world=None)
+        ref, rrel, ract = _grads_after_backward(ref_tr, _batch(0, 2))
+        tr = _build(world=None)
+        red = GradReducer(engine().grad_arena, bucket_bytes=32 << 20, force_collectives=True)
+        tr.world = red
+        engine().grad_ready_hook = red.on_grad
+        g1, rel, act = _grads_after_backward(tr, _batch(0, 2))          # learning step: every bucket reduced at finish()
+        g2, _, _ = _grads_after_backward(tr, _batch(0, 2))              # overlapped step: buckets go out during backward
+        early = sum(1 for i, b in enumerate(red.launch_order) if b != len(red.bounds) - 1 - i)
+        seen = torch.ones(1, device="cuda")
+        dist.all_reduce(seen)
+        ok = (torch.allclose(g1, ref, rtol=1e-4, atol=1e-6 * ref.abs().max().item()) and
+              torch.allclose(g2, ref, rtol=1e-4, atol=1e-6 * ref.abs().max().item()) and abs(rel - rrel) < 1e-5 * abs(rrel)
+              and len(red.launch_order) == len(red.bounds) and int(seen.item()) == 1)
+        q.put("ok buckets=%d out_of_order=%d" % (len(red.bounds), early) if ok else
+              "MISMATCH %g %g" % ((g1 - ref).abs().max().item(), (g2 - ref).abs().max().item()))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put("FAIL " + traceback.format_exc()[-1500:])
+
+
+def test_grad_reducer_through_rccl_single_rank_equals_the_plain_step():
+    """The reducer's RCCL path (backend "nccl", one rank, collectives forced): the comm stream, the per-bucket waits on every
+    writer stream and the in-arena all-reduces run exactly as with N ranks; a one-rank SUM is the identity, so the gradients
+    must equal the step without a reducer - in the learning step and in the overlapped step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert res.startswith("ok"), res

@@ -937,3 +937,17 @@ def test_conv2_dgrad_at_bench_shape_integer_exact_and_bf16(K):
     err = (dx.view(-1, C)[rows].float() - ref).abs().max().item()
     print("conv2 dgrad B=32: max |dx - ref| = %.3e (|ref| max %.3f)" % (err, ref.abs().max().item()))
     assert err <= 2 ** -8 * ref.abs().max().item() + 1e-3
+
+
+def test_matcher_forward_rejects_class_ids_outside_the_logits():
+    """matcher.py:74: out_prob[:, tgt_ids] raises IndexError for a label >= num_classes; the kernel itself clamps the read."""
+    from shg_vqa_amd.matcher import HungarianMatcher
+    m = HungarianMatcher(cost_class=1, loss_hg_per_frame=True, clip_len=2)
+    logits = torch.randn(1, 8, 5, device=DEV)
+    ok = [{"labels": [torch.tensor([1, 4]), torch.tensor([], dtype=torch.int64)]}]
+    out = m({"pred_logits": logits}, ok)
+    assert len(out) == 2 and len(out[0][0]) == 2 and len(out[1][0]) == 0
+    with pytest.raises(IndexError):
+        m({"pred_logits": logits}, [{"labels": [torch.tensor([1, 5]), torch.tensor([2])]}])
+    with pytest.raises(ValueError):
+        m({"pred_logits": logits}, [{"labels": [torch.tensor([1, 2, 3, 4, 1]), torch.tensor([2])]}])

@@ -429,8 +429,9 @@ def test_overlapped_optimizer_update_gives_the_same_parameters():
 
 
 def test_whole_step_hipgraph_replay_matches_eager_steps():
-    """AGQA.capture / train_step_graphed (bench.py --exec graph): the optimiser step captured into one hipGraph (model
-    branches inline, weight gradients on their side stream) gives the losses of eager multi-stream steps."""
+    """AGQA.capture / train_step_graphed (bench.py --exec graph): the optimiser step captured into one hipGraph (the action
+    decoder / heads / set losses on their branch stream, weight gradients on theirs, the language branch inline) gives the
+    losses of eager multi-stream steps."""
     from oracle import shg_ref
     from shg_vqa_amd.transformer import MultiheadAttention
     cfg = shg_ref.Cfg()
