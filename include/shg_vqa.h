@@ -201,6 +201,20 @@ int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o
 int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
              int accumulate, void* stream);
+/* Weight gradients of n nn.Linear layers in as few launches as possible:  gw[n_out, n_in] += dy[rows, n_out]^T . x[rows, n_in]
+ * (fp32 gradient, row stride n_in; dy / x row strides ldy / ldx).  Runs of bf16 problems with rows % 64 == 0 go out as ONE
+ * grid of 256 x 256 tiles over all of them (a decoder layer's eight weight gradients are 9-24 tiles each: alone none fills a
+ * sixth of the chip; split along the rows with fp32 atomics only when even the whole group is small); anything else falls
+ * back to shg_gemm per problem.  Replaces the dW part of the backward of modeling_capsbert.py:373-375, :427, :466, :481 and
+ * transformer.py:192-196. */
+typedef struct shg_wgrad_problem {
+    const void* dy;
+    const void* x;
+    float* gw;
+    int64_t rows, n_out, n_in, ldy, ldx;
+} shg_wgrad_problem_t;
+int shg_wgrad_group(const shg_wgrad_problem_t* problems, int n, int dtype, void* stream);
+
 /* C = act(A . B + bias) with the activation in the epilogue and, when `pre` is given, the pre-activation
  * values A . B + bias written to pre [M, N] (row stride N, dtype_c) for the backward pass: BertIntermediate's
  * Linear + erf-GELU (modeling_capsbert.py:472-475, :127-133) and the heads' Linear + GELU (agqa_model.py:105-110)
@@ -308,6 +322,11 @@ typedef struct shg_exec shg_exec_t;
 int shg_abi_sizeof(int which);
 shg_exec_t* shg_exec_create(int n_events);
 void shg_exec_destroy(shg_exec_t* ex);
+/* Deferred weight gradients (shg_run_t.defer_wgrad): number of 256 x 256 output tiles queued so far, and the flush: orders
+ * `wgrad_stream` behind every stream that produced a queued operand, then issues the queue with shg_wgrad_group and the
+ * bias column sums behind it.  Returns 0 with an empty queue. */
+int64_t shg_exec_pending_tiles(const shg_exec_t* ex);
+int shg_exec_flush_wgrads(shg_exec_t* ex, int dtype, void* wgrad_stream);
 
 typedef struct shg_run {
     int32_t dtype;            /* SHG_F32 / SHG_BF16: activations and operands */
@@ -316,6 +335,9 @@ typedef struct shg_run {
     void* wgrad_stream;       /* hipStream_t for weight gradients, or NULL: inline on `stream` */
     shg_exec_t* exec;         /* needed when wgrad_stream is set */
     const uint64_t* seed_state;
+    int32_t defer_wgrad;      /* != 0 (needs wgrad_stream): weight / bias gradients are queued on `exec` instead of launched; the
+                                 caller keeps their operands alive and calls shg_exec_flush_wgrads (grouped launches) */
+    int32_t pad_;
 } shg_run_t;
 
 typedef struct shg_linear {

@@ -58,6 +58,9 @@ _SIGNATURES = {
     "shg_bias_act_drop_res_ln_fwd_pos": ([P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, F, F, P, U, P], c_int),
     "shg_exec_create": ([I], c_void_p),
     "shg_exec_destroy": ([P], None),
+    "shg_exec_pending_tiles": ([P], c_int64),
+    "shg_exec_flush_wgrads": ([P, I, P], c_int),
+    "shg_wgrad_group": ([P, I, I, P], c_int),
     "shg_abi_sizeof": ([I], c_int),
     "shg_attn_sublayer_saved_bytes": ([I, I, I, I, I, I], c_int64),
     "shg_attn_sublayer_scratch_bytes": ([I, I, I, I, I, I], c_int64),
@@ -101,7 +104,12 @@ class DecoderLayerT(ctypes.Structure):
 
 class RunT(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int32), ("training", ctypes.c_int32), ("stream", c_void_p), ("wgrad_stream", c_void_p),
-                ("exec", c_void_p), ("seed_state", c_void_p)]
+                ("exec", c_void_p), ("seed_state", c_void_p), ("defer_wgrad", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class WgradProblemT(ctypes.Structure):
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("gw", c_void_p), ("rows", c_int64), ("n_out", c_int64), ("n_in", c_int64),
+                ("ldy", c_int64), ("ldx", c_int64)]
 
 
 _ABI_STRUCTS = [RunT, LinearT, NormT, AttnSublayerT, FfnSublayerT, DecoderLayerT]

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .agqa_eval import AGQAEvaluator as Evaluator          # per-category tables, agqa_data.py:341-1146
 from .agqa_model import AGQAModel
 from .engine import engine
 from .entry import clip_targets_device, frame_segment_ids
@@ -32,13 +33,39 @@ class SyntheticAGQA(torch.utils.data.Dataset):
     num_situations, num_rel, num_act = 16, 8, 3
     rel_classes = 456
 
+    QTYPES = ("obj-rel", "rel-act", "obj-act", "superlative", "sequencing", "exists", "duration-comparison", "action-recognition")
+    SEMANTIC = ("object", "relation", "action")
+    STRUCTURAL = ("query", "compare", "choose", "logic", "verify")
+
     def __init__(self, n=256, seed=1234, feat_pool=8):
         self.n, self.seed = n, seed
         g = torch.Generator().manual_seed(seed)
         self.feat_pool = [torch.randn(2048, 16, 7, 7, generator=g) for _ in range(feat_pool)]
+        self.answerVocab = {"answer_%03d" % k: k for k in range(self.num_answers)}       # agqa_data.py:343: answer string -> index
+        self._id2datum = None
 
     def __len__(self):
         return self.n
+
+    def answer_index(self, i):
+        return (self.seed * 31 + i * 7919) % self.num_answers
+
+    @property
+    def id2datum(self):
+        """Annotation records with the fields AGQAEvaluator reads (agqa_data.py:341-1146), a fixed function of the index."""
+        if self._id2datum is None:
+            d = {}
+            for i in range(self.n):
+                a = self.answer_index(i)
+                d[i] = dict(question_id=i, question="synthetic question %d" % i, answer="answer_%03d" % a,
+                            ans_type="binary" if a % 3 == 0 else "open",
+                            **{"global": [self.QTYPES[i % 8]] + ([self.QTYPES[(i // 8) % 8]] if i % 5 == 0 else [])},
+                            semantic=self.SEMANTIC[i % 3], structural=self.STRUCTURAL[i % 5],
+                            nc_seq=int(i % 4 == 0), nc_sup=int(i % 4 == 1), nc_dur=int(i % 4 == 2), nc_objrel=int(i % 4 == 3),
+                            i_obj=int(i % 2 == 0), i_act=int(i % 3 == 0), i_temp=int(i % 5 == 0),
+                            indirect=int(i % 2 == 1), direct_equiv=(i - 1 if i % 2 == 1 else None))
+            self._id2datum = d
+        return self._id2datum
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 7919 + i)
@@ -61,25 +88,11 @@ class SyntheticAGQA(torch.utils.data.Dataset):
         rel, rel_len = ragged(self.num_rel, self.rel_classes)
         act, act_len = ragged(self.num_act, len(self.action_classes))
         target = torch.zeros(self.num_answers)
-        target[int(torch.randint(0, self.num_answers, (1,), generator=g))] = 1.0
+        target[self.answer_index(i)] = 1.0
         return dict(ques_id=i, feat=self.feat_pool[i % len(self.feat_pool)], pos=torch.ones(393),
                     input_ids=ids, input_mask=mask, segment_ids=torch.zeros(40, dtype=torch.int64),
                     rel_triplets=rel, lengths=rel_len, act_tokens=act, act_lengths=act_len,
                     hg_mask=torch.cat([(act > 0), (rel > 0)], dim=1).float(), target=target)
-
-
-class Evaluator:
-    """Top-1 answer accuracy (the per-category tables of AGQAEvaluator, agqa_data.py:341-1101, need the
-    real annotations and are out of scope)."""
-
-    def __init__(self, dataset):
-        self.dataset = dataset
-
-    def evaluateOverall(self, quesid2ans):
-        if not quesid2ans:
-            return 0.0
-        hit = sum(int(self.dataset[q]["target"].argmax()) == int(a) for q, a in quesid2ans.items())
-        return hit / len(quesid2ans)
 
 
 def get_tuple(splits, bs, shuffle=False, drop_last=False, n=256, seed=1234):
@@ -363,6 +376,33 @@ class AGQA:
     def evaluate(self, eval_tuple, dump=None):
         return eval_tuple.evaluator.evaluateOverall(self.predict(eval_tuple, dump))
 
+    def evaluateAllQtypes(self, eval_tuple, dump=None):
+        """agqaHGQA.py:808-811: target-free inference, then the 31 per-category accuracies."""
+        return eval_tuple.evaluator.evaluateAllQtypes(self.test(eval_tuple, dump))
+
+    def evaluateTestSplits(self, eval_tuple, dump=None):
+        """agqaHGQA.py:816-838: the AGQA test splits selected by --indirectRef / --novelComp / --compSteps."""
+        ev = eval_tuple.evaluator
+        q2a = self.test(eval_tuple, dump)
+        if getattr(self.args, "indirect_ref", False):
+            recall, precision_qs = ev.evaluateIndirectRef(q2a)
+            return ev.evaluateAllQtypes(q2a), recall, ev.evaluatePrecision(precision_qs)
+        if getattr(self.args, "novel_comp", False):
+            return ev.evaluateNovelComp(q2a)
+        if getattr(self.args, "comp_steps", False):
+            return ev.evaluateCompSteps(q2a)
+        return ev.evaluateAllQtypes(q2a)
+
+    @staticmethod
+    def oracle_score(data_tuple):
+        """agqaHGQA.py:843-856: the score of the ground-truth labels themselves (1.0 unless the answer vocabulary drops labels)."""
+        dset, loader, evaluator = data_tuple
+        quesid2ans = {}
+        for batch in loader:
+            for qid, l in zip(batch["ques_id"].tolist(), batch["target"].argmax(1).tolist()):
+                quesid2ans[qid] = int(l)
+        return evaluator.evaluate(quesid2ans)
+
     def save(self, name):
         os.makedirs(self.output, exist_ok=True)
         engine().wait_params_ready()
@@ -376,3 +416,72 @@ class AGQA:
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
         self.model.load_state_dict(sd, strict=True)
         engine().refresh_shadows()
+
+
+# ------------------------------------------------------------------ command line (agqaHGQA.py:877-1075)
+def _report_test(agqa, args, split):
+    from .agqa_eval import ALL_QTYPES, COMP_STEPS, INDIRECT, NOVEL_COMP, format_report
+    data = get_tuple(split, bs=args.batch_size, shuffle=False, drop_last=False)
+    out = os.path.join(args.output, "%s_predictions.json" % split)
+    os.makedirs(args.output, exist_ok=True)
+    if split == "valid":
+        print(format_report("Valid HQ results:", ALL_QTYPES, agqa.evaluateAllQtypes(data, dump=None)), flush=True)
+    elif getattr(args, "indirect_ref", False):
+        allq, recall, prec = agqa.evaluateTestSplits(data, dump=out)
+        print(format_report("\nTest Results:", ALL_QTYPES, allq), flush=True)
+        print(format_report("\nTest Indirect References (recall):", INDIRECT, recall), flush=True)
+        print(format_report("\nTest Precision:", INDIRECT, prec), flush=True)
+    elif getattr(args, "novel_comp", False):
+        print(format_report("\nTest Novel Compositions:", NOVEL_COMP, agqa.evaluateTestSplits(data, dump=out)), flush=True)
+    elif getattr(args, "comp_steps", False):
+        print(format_report("\nTest Compositional Steps:", COMP_STEPS, agqa.evaluateTestSplits(data, dump=out)), flush=True)
+    else:
+        print(format_report("\nTest:", ALL_QTYPES, agqa.evaluateAllQtypes(data, dump=out)), flush=True)
+
+
+def main(argv=None):
+    """`python -m shg_vqa_amd.agqa_hgqa <flags of param.py>`: train / --test valid,test like the reference's __main__.
+    --multiGPU: one process per GPU (the reference wraps the model in nn.DataParallel, agqaHGQA.py:124-129): this process
+    re-launches itself under torch.distributed.run BEFORE anything touches the GPU and exits with the children's code."""
+    import sys
+    from .param import parse_args
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.multiGPU and "LOCAL_RANK" not in os.environ:
+        import subprocess
+        n = torch.cuda.device_count()              # (counting devices does not initialise the runtime)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(max(n, 1)), "--master-addr",
+               "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), "-m", "shg_vqa_amd.agqa_hgqa"] + argv
+        return subprocess.call(cmd)
+    world = None
+    if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        local = int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from .engine import reset_engine
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    reset_engine(compute_dtype=torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32, device=dev, seed=args.seed + rank)
+    torch.manual_seed(args.seed)                   # identical --fromScratch initialisation on every rank
+    train = get_tuple(args.train, args.batch_size, shuffle=True, drop_last=True, seed=1234 + rank)
+    valid = get_tuple(args.valid, args.batch_size, shuffle=False, drop_last=False) if args.valid else None
+    agqa = AGQA(args, train_tuple=train, valid_tuple=valid)
+    if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from .ddp import GradReducer
+        agqa.world = GradReducer(engine().grad_arena)
+        engine().grad_ready_hook = agqa.world.on_grad
+    if args.load is not None:
+        agqa.load(args.load)
+    if args.test is not None:
+        for split in ("valid", "test"):
+            if split in args.test:
+                _report_test(agqa, args, split)
+        return 0
+    print("Splits in Train data:", args.train, "| oracle score of the labels: %0.2f" % (100.0 * AGQA.oracle_score(train)), flush=True)
+    agqa.train(train, valid)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

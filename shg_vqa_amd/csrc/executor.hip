@@ -13,15 +13,26 @@
 //   decoder              TransformerDecoder.forward over forward_post layers (transformer.py:86-124, :212-233)
 // Weight gradients go to run->wgrad_stream behind an event recorded on the main stream right after their operands were
 // enqueued there (dW only feeds the optimiser; the input-gradient chain does not wait for it).
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
 
 namespace shg {
 
+struct ColsumJob {
+    const void* x;
+    int64_t rows, cols, ld;
+    float* out;
+};
 struct Exec {
     std::vector<hipEvent_t> events;
     size_t cursor = 0;
+    // deferred weight gradients (shg_run_t.defer_wgrad): problems, bias column sums, and the streams their operands come from
+    std::vector<shg_wgrad_problem_t> wq;
+    std::vector<ColsumJob> cq;
+    std::vector<void*> producers;
+    int64_t pending_tiles = 0;
 };
 
 static inline int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
@@ -71,22 +82,37 @@ static int fork_wgrad(const shg_run_t* R, void** out) {
     return 0;
 }
 
+// (shg_colsum_accumulate takes at most 512 16-byte chunks per row: wider outputs go in column slices)
+static int colsum_sliced(const void* dy, int dtype, int64_t rows, int64_t n_out, int64_t ldy, float* gb, void* st) {
+    const int64_t es = esize(dtype), max_cols = 512 * (16 / es);
+    for (int64_t c0 = 0; c0 < n_out; c0 += max_cols) {
+        const int64_t nc = n_out - c0 < max_cols ? n_out - c0 : max_cols;
+        CK(shg_colsum_accumulate((const char*)dy + c0 * es, dtype, rows, (int)nc, ldy, gb + c0, st));
+    }
+    return 0;
+}
+
 // dW += dy^T x ; db += colsum(dy).   dy [rows, n_out] (row stride ldy), x [rows, n_in] (row stride ldx)
 static int wgrad(const shg_run_t* R, const shg_linear_t& lin, const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t rows,
                  int64_t n_out, int64_t n_in, bool with_bias) {
     const bool want_b = with_bias && lin.gb;
     if (!lin.gw && !want_b) return 0;
+    if (R->defer_wgrad && R->wgrad_stream && R->exec) {          // queued: shg_exec_flush_wgrads issues them grouped
+        Exec* ex = reinterpret_cast<Exec*>(R->exec);
+        if (lin.gw) {
+            ex->wq.push_back(shg_wgrad_problem_t{dy, x, lin.gw, rows, n_out, n_in, ldy, ldx});
+            ex->pending_tiles += ((n_out + 255) / 256) * ((n_in + 255) / 256);
+        }
+        if (want_b) ex->cq.push_back(ColsumJob{dy, rows, n_out, ldy, lin.gb});
+        bool seen = false;
+        for (void* p : ex->producers) seen = seen || p == R->stream;
+        if (!seen) ex->producers.push_back(R->stream);
+        return 0;
+    }
     void* st = nullptr;
     CK(fork_wgrad(R, &st));
     if (lin.gw) CK(shg_gemm(dy, x, lin.gw, nullptr, R->dtype, SHG_F32, n_out, n_in, rows, ldy, ldx, n_in, 0, 0, 1, st));
-    if (want_b) {
-        // (shg_colsum_accumulate takes at most 512 16-byte chunks per row: wider outputs go in column slices)
-        const int64_t es = esize(R->dtype), max_cols = 512 * (16 / es);
-        for (int64_t c0 = 0; c0 < n_out; c0 += max_cols) {
-            const int64_t nc = n_out - c0 < max_cols ? n_out - c0 : max_cols;
-            CK(shg_colsum_accumulate((const char*)dy + c0 * es, R->dtype, rows, (int)nc, ldy, lin.gb + c0, st));
-        }
-    }
+    if (want_b) CK(colsum_sliced(dy, R->dtype, rows, n_out, ldy, lin.gb, st));
     return 0;
 }
 
@@ -429,6 +455,39 @@ extern "C" shg_exec_t* shg_exec_create(int n_events) {
         }
     }
     return reinterpret_cast<shg_exec_t*>(ex);
+}
+
+extern "C" int64_t shg_exec_pending_tiles(const shg_exec_t* h) {
+    const Exec* ex = reinterpret_cast<const Exec*>(h);
+    return ex ? ex->pending_tiles : 0;
+}
+
+extern "C" int shg_exec_flush_wgrads(shg_exec_t* h, int dtype, void* wgrad_stream) {
+    Exec* ex = reinterpret_cast<Exec*>(h);
+    if (!ex) return fail_arg("exec_flush_wgrads: null handle");
+    if (ex->wq.empty() && ex->cq.empty()) return 0;
+    if (!wgrad_stream) return fail_arg("exec_flush_wgrads: deferred weight gradients need the weight-gradient stream");
+    if (ex->events.empty()) return fail_arg("exec_flush_wgrads: shg_exec_t has no events");
+    // sort: problems with equal row counts next to each other (a group shares its K length best), largest first
+    std::stable_sort(ex->wq.begin(), ex->wq.end(), [](const shg_wgrad_problem_t& a, const shg_wgrad_problem_t& b) { return a.rows > b.rows; });
+    for (void* p : ex->producers) {
+        if (p == wgrad_stream) continue;
+        hipEvent_t ev = ex->events[ex->cursor];
+        ex->cursor = (ex->cursor + 1) % ex->events.size();
+        hipError_t e = hipEventRecord(ev, (hipStream_t)p);
+        if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)wgrad_stream, ev, 0);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return (int)e; }
+    }
+    int rc = shg_wgrad_group(ex->wq.data(), (int)ex->wq.size(), dtype, wgrad_stream);
+    for (size_t i = 0; rc == 0 && i < ex->cq.size(); ++i) {
+        const ColsumJob& c = ex->cq[i];
+        rc = colsum_sliced(c.x, dtype, c.rows, c.cols, c.ld, c.out, wgrad_stream);
+    }
+    ex->wq.clear();
+    ex->cq.clear();
+    ex->producers.clear();
+    ex->pending_tiles = 0;
+    return rc;
 }
 
 extern "C" void shg_exec_destroy(shg_exec_t* h) {

@@ -907,9 +907,11 @@ __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_
     return streamk_plan(sk.n_tiles, nk_all, (int)blockIdx.x, (int)gridDim.x, seg, sk.sigma);
 }
 
+// (the body is a device function so that the plain launch and the grouped launch - many small problems, one grid - share it:
+//  bx / by = this workgroup's tile slot and split-K part inside ITS problem, gx / gy = that problem's tile and split counts)
 template <typename TC, typename SrcA, typename SrcB, bool SK = false>
-__global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
-                                                    int grid_m, StreamK sk) {
+__device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, int grid_m, StreamK sk,
+                                           const int bx, const int by, const int gx, const int gy) {
     static_assert(!SrcA::DYN, "only the B operand may gather per K-tile");
     using T = bf16_t;
     using TL = Tile64<T>;
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
     const int64_t nk_all = K / BK;
     // grid_m < 0: walk M fastest instead (few row tiles, many column tiles - the weight-gradient shapes - so
     // that the tiles sharing a B column-panel sit next to each other)
-    const int64_t n_tiles = SK ? (int64_t)sk.n_tiles : (int64_t)gridDim.x, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
+    const int64_t n_tiles = SK ? (int64_t)sk.n_tiles : (int64_t)gx, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
 
 #pragma nounroll
     for (int seg = 0; seg < (SK ? 64 : 1); ++seg) {
@@ -934,11 +936,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
         if (d.nk == 0) break;
         tile = d.tile; kb = d.kb; nk = d.nk;
     } else {
-        const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = blockIdx.x % 8;
-        tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + blockIdx.x / 8;
+        const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = bx % 8;
+        tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + bx / 8;
         // K range of this workgroup (gridDim.y > 1: split-K, partial sums added with atomics by the epilogue)
-        const int64_t per_split = (nk_all + gridDim.y - 1) / gridDim.y;
-        kb = (int64_t)blockIdx.y * per_split;
+        const int64_t per_split = (nk_all + gy - 1) / gy;
+        kb = (int64_t)by * per_split;
         nk = min(nk_all, kb + per_split) - kb;               // K-tiles of this workgroup, numbered 0 .. nk-1 below
         if (nk <= 0) return;
     }
@@ -1181,6 +1183,39 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
     }
 }
 
+template <typename TC, typename SrcA, typename SrcB, bool SK = false>
+__global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
+                                                    int grid_m, StreamK sk) {
+    gemm8_body<TC, SrcA, SrcB, SK>(sa, sb, ep, M, N, K, grid_m, sk, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+}
+
+// Grouped launch: up to G8_MAX_GROUP independent problems (the weight gradients of several layers, each far too small to
+// fill 256 CUs with 256 x 256 tiles) in ONE grid.  Every problem owns a contiguous, 8-aligned range of block indices
+// [first, first + tiles * split) - 8-aligned so that the block -> XCD mapping of the tile walk stays what the body assumes.
+constexpr int G8_MAX_GROUP = 14;
+template <typename TC, typename SrcA, typename SrcB> struct G8Entry {
+    SrcA sa;
+    SrcB sb;
+    Epilogue<TC> ep;
+    int64_t M, N, K;
+    int grid_m, tiles, split, first;
+};
+template <typename TC, typename SrcA, typename SrcB> struct G8Group {
+    int n;
+    G8Entry<TC, SrcA, SrcB> e[G8_MAX_GROUP];
+};
+template <typename TC, typename SrcA, typename SrcB>
+__global__ __launch_bounds__(512) void gemm8_group_kernel(G8Group<TC, SrcA, SrcB> grp) {
+    int p = 0;
+    for (int i = 1; i < grp.n; ++i)
+        if ((int)blockIdx.x >= grp.e[i].first) p = i;
+    const G8Entry<TC, SrcA, SrcB>& e = grp.e[p];
+    const int local = (int)blockIdx.x - e.first;
+    if (local >= e.tiles * e.split) return;                    // padding of the range up to a multiple of 8
+    gemm8_body<TC, SrcA, SrcB, false>(e.sa, e.sb, e.ep, e.M, e.N, e.K, e.grid_m, StreamK{nullptr, nullptr, 0, 100}, local % e.tiles,
+                                      local / e.tiles, e.tiles, e.split);
+}
+
 // Partial-sum slots and flags of the stream-K launches live in a CALLER-OWNED workspace (shg_streamk_workspace_bytes /
 // shg_streamk_workspace_init; include/shg_vqa.h): 4 KiB of flags followed by STREAMK_SLOTS partial tiles.  One workspace serves
 // the launches of ONE stream at a time (launches on a stream are ordered; two streams could overlap and need one each).
@@ -1419,6 +1454,71 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
     }
     Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0, nullptr, nullptr, dthr, dscale, seed_state, stream_id};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
+}
+
+// Weight gradients of several nn.Linear layers in one grid (include/shg_vqa.h: shg_wgrad_group).
+extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtype, void* stream) {
+    if (!probs || n < 0) return fail_arg("wgrad_group: bad argument");
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("wgrad_group: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    using SA = PlainSrc<bf16_t, false>;
+    using Grp = G8Group<float, SA, SA>;
+    static const int mode = []() { const char* e = getenv("SHG_WGRAD_GROUP"); return e ? atoi(e) : 1; }();
+    int i = 0;
+    while (i < n) {
+        // take a run of problems the 8-phase kernel can do: bf16, whole 64-row K-tiles, 16-byte aligned rows
+        int j = i;
+        int64_t tiles = 0;
+        auto ok8 = [&](const shg_wgrad_problem_t& q) {
+            return mode && dtype == SHG_BF16 && q.rows % BK == 0 && q.rows >= 2 * BK && q.n_out % 8 == 0 && q.n_in % 8 == 0 && q.ldy % 8 == 0 &&
+                   q.ldx % 8 == 0 && al16(q.dy) && al16(q.x) && al16(q.gw) && q.n_in % 4 == 0 &&
+                   (int64_t)BK * q.ldy * 2 < ((int64_t)1 << 32) && (int64_t)BK * q.ldx * 2 < ((int64_t)1 << 32);
+        };
+        while (j < n && j - i < G8_MAX_GROUP && ok8(probs[j])) {
+            tiles += ((probs[j].n_out + 255) / 256) * ((probs[j].n_in + 255) / 256);
+            ++j;
+        }
+        if (j - i >= 2 && tiles >= 48) {
+            Grp g{};
+            g.n = j - i;
+            int first = 0;
+            for (int k = i; k < j; ++k) {
+                const shg_wgrad_problem_t& q = probs[k];
+                if (!q.dy || !q.x || !q.gw || q.rows <= 0 || q.n_out <= 0 || q.n_in <= 0) return fail_arg("wgrad_group: bad problem");
+                G8Entry<float, SA, SA>& e = g.e[k - i];
+                const int64_t gm = (q.n_out + 255) / 256, gn = (q.n_in + 255) / 256, nk = q.rows / BK;
+                // split-K only when the whole group cannot fill the chip: partial tiles meet in C through fp32 atomics
+                int split = 1;
+                if (tiles < 160) split = (int)std::max<int64_t>(1, std::min<int64_t>((224 + tiles - 1) / tiles, nk / 12));
+                e.sa = SA{(const bf16_t*)q.dy, q.ldy, 0, q.n_out, q.rows};
+                e.sb = SA{(const bf16_t*)q.x, q.ldx, 0, q.n_in, q.rows};
+                e.ep = Epilogue<float>{q.gw, q.n_in, nullptr, nullptr, SHG_ACT_NONE, 1, 1, nullptr, split > 1 ? 1 : 0};
+                e.M = q.n_out; e.N = q.n_in; e.K = q.rows;
+                e.grid_m = tile_order(gm, gn);
+                e.tiles = (int)(gm * gn);
+                e.split = split;
+                e.first = first;
+                first += (e.tiles * split + 7) / 8 * 8;
+            }
+            auto kern = gemm8_group_kernel<float, SA, SA>;
+            const size_t lds = std::max<size_t>(2 * 8 * Tile64<bf16_t>::BYTES, (size_t)8 * 64 * STG_LD * 4);
+            static std::atomic<uint64_t> raised{0};
+            if (!lds_raised(raised))
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)first), dim3(512), lds, st, g);
+            if (int e = check_launch("wgrad_group")) return e;
+            i = j;
+            continue;
+        }
+        // not groupable (fp32 parity mode, ragged row count, a lone problem): the plain weight-gradient GEMM
+        const int end = j > i ? j : i + 1;
+        for (int k = i; k < end; ++k) {
+            const shg_wgrad_problem_t& q = probs[k];
+            if (int e = shg_gemm(q.dy, q.x, q.gw, nullptr, dtype, SHG_F32, q.n_out, q.n_in, q.rows, q.ldy, q.ldx, q.n_in, 0, 0, 1, stream)) return e;
+        }
+        i = end;
+    }
+    return 0;
 }
 
 // host evaluation of the device-side work split (tests/test_abi.py checks that heads and tails cover every K-tile of every

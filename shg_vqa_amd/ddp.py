@@ -174,6 +174,12 @@ class GradReducer:
 
     def finish(self):
         """After backward: reduce whatever is left, then make the compute stream wait for the collectives."""
+        if self.use_streams:
+            try:                                     # weight gradients still queued for a grouped launch report on issue
+                from .ops import flush_wgrads
+                flush_wgrads()
+            except ImportError:
+                pass
         if self.expected is not None and self.counts != self.expected:
             bad = [b for b in range(len(self.bounds)) if self.counts[b] != self.expected[b]]
             raise RuntimeError("GradReducer: buckets %s were written %s times, the learning step wrote them %s times"

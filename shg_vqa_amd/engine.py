@@ -69,6 +69,11 @@ class Engine:
         self.deferred_branch = None
         self.grad_dirty = False           # gradients written since the arena was last zeroed
         self.unjoined = set()             # side streams that received work since the last join_side_streams() (fork / join ledger)
+        # weight gradients of the executor calls are queued and go out as grouped launches once ~a chip's worth of 256 x 256
+        # tiles is pending (SHG_WGRAD_DEFER=0: every weight gradient is its own launch, issued at once)
+        self.defer_wgrads = os.environ.get("SHG_WGRAD_DEFER", "1") != "0"
+        self.wgrad_flush_tiles = int(os.environ.get("SHG_WGRAD_FLUSH_TILES", "224"))
+        self.pending_keep, self.pending_params = [], []
         self._exec = None                 # shg_exec_t* of the sub-layer executor (event ring for the weight-gradient stream)
         self._run = None                  # persistent shg_run_t handed to every executor call
         self.params_ready_event = None
@@ -121,10 +126,45 @@ class Engine:
         R.stream = _stream()
         side = self.wgrad_stream()
         R.wgrad_stream = side.cuda_stream if side is not None else None
+        R.defer_wgrad = 1 if (side is not None and self.defer_wgrads) else 0
         if side is not None:
             self.unjoined.add(side.cuda_stream)
         R.seed_state = self.seed_state.data_ptr()
         return ctypes.addressof(R)
+
+    def after_backward_call(self, keep, params):
+        """Bookkeeping after an executor backward call.  keep: buffers its weight-gradient launches read (they may still be
+        queued: shg_run_t.defer_wgrad - hold them until the flush; the launches already issued read them on the side
+        stream: record it); params: parameters whose gradient slices the call finished (or queued)."""
+        side = self.wgrad_stream()
+        if side is not None:
+            for t in keep:
+                if t is not None:
+                    t.record_stream(side)
+        self.grad_dirty = True
+        if self._run is not None and self._run.defer_wgrad:
+            self.pending_keep.append(keep)
+            self.pending_params.extend(params)
+            from . import _lib
+            if _lib.lib().shg_exec_pending_tiles(self._exec) >= self.wgrad_flush_tiles:
+                self.flush_native_wgrads()
+        elif self.grad_ready_hook is not None:
+            for p in params:
+                self.grad_written(p)
+
+    def flush_native_wgrads(self):
+        """Issues the queued weight gradients (grouped launches on the side stream) and tells the reducer."""
+        if self._exec is None:
+            return
+        from . import _lib
+        if self.pending_keep or _lib.lib().shg_exec_pending_tiles(self._exec) > 0:
+            side = self.wgrad_stream()
+            _lib.call("shg_exec_flush_wgrads", self._exec, self._run.dtype, side.cuda_stream if side is not None else None)
+            self.pending_keep.clear()
+            if self.grad_ready_hook is not None:
+                for p in self.pending_params:
+                    self.grad_written(p)
+            self.pending_params.clear()
 
     def note_fork(self, stream):
         """Fork / join ledger: `stream` has received work that the step's origin stream has not waited for yet.
@@ -233,6 +273,7 @@ class Engine:
         if self.deferred_wgrads:
             from . import ops
             ops.flush_wgrads()
+        self.flush_native_wgrads()
         cur = torch.cuda.current_stream()
         joined = set()
         for s in self.side_streams():

@@ -343,6 +343,23 @@ def gemm(a, b, out, bias=None, a_kmajor=True, b_kmajor=True, accumulate=False):
     return out
 
 
+def wgrad_group(problems):
+    """problems: list of (dy [rows, n_out], x [rows, n_in], gw fp32 [n_out, n_in]); gw += dy^T x for each, grouped launches
+    where the shapes allow (shg_wgrad_group)."""
+    n = len(problems)
+    arr = (_lib.WgradProblemT * max(n, 1))()
+    for e, (dy, x, gw) in zip(arr, problems):
+        _dev(dy, x, gw)
+        _need(dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0] and
+              dy.dtype == x.dtype, "wgrad_group: dy [rows, n_out] and x [rows, n_in] of one dtype")
+        _need(gw.dtype == torch.float32 and gw.is_contiguous() and tuple(gw.shape) == (dy.shape[1], x.shape[1]), "gw fp32 [n_out, n_in]")
+        e.dy, e.x, e.gw = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
+        e.rows, e.n_out, e.n_in, e.ldy, e.ldx = dy.shape[0], dy.shape[1], x.shape[1], dy.stride(0), x.stride(0)
+    if n:
+        import ctypes
+        _lib.call("shg_wgrad_group", ctypes.addressof(arr), n, _dt(problems[0][0]), _stream())
+
+
 _conv_ws = {}
 
 

@@ -191,6 +191,7 @@ def flush_wgrads():
     """Issues the queued weight gradients on the side stream, behind everything their producer streams
     have enqueued so far."""
     E = engine()
+    E.flush_native_wgrads()
     q, E.deferred_wgrads = E.deferred_wgrads, []
     if not q:
         return
@@ -830,25 +831,6 @@ def _trainable(*ps):
     return [p for p in ps if p is not None and p._shg_grad is not None]
 
 
-def _note_grads(params):
-    """Tells the engine (and through it the data-parallel reducer) that these gradient slices are final for this
-    pass: every launch that writes them has been enqueued when the executor call returns."""
-    E = engine()
-    E.grad_dirty = True
-    if E.grad_ready_hook is not None:
-        for p in params:
-            E.grad_written(p)
-
-
-def _keep_for_side_stream(*tensors):
-    """Buffers the weight-gradient stream still reads after the call returned must not be recycled under it."""
-    side = engine().wgrad_stream()
-    if side is not None:
-        for t in tensors:
-            if t is not None:
-                t.record_stream(side)
-
-
 def _bytes(n, dev):
     return torch.empty(n, dtype=torch.uint8, device=dev)
 
@@ -968,8 +950,7 @@ class _FFNSublayer(torch.autograd.Function):
         scratch = _bytes(_lib.lib().shg_ffn_sublayer_scratch_bytes(dtc, rows, H, F), x2.device)
         _lib.call("shg_ffn_sublayer_bwd", _ADDR(P.cstruct()), E.run_addr(dtc), rows, H, F, x2.data_ptr(), saved.data_ptr(),
                   dy2.data_ptr(), _ptr(dx), scratch.data_ptr(), sid)
-        _keep_for_side_stream(x2, saved, scratch)
-        _note_grads(P.trainable)
+        E.after_backward_call((x2, saved, scratch), P.trainable)
         return (dx.view(shape) if dx is not None else None), None, None
 
 
@@ -1021,8 +1002,7 @@ class _AttnSublayer(torch.autograd.Function):
         scratch = _bytes(_lib.lib().shg_attn_sublayer_scratch_bytes(L.mode, dtc, B, Sq, Sk, P.heads), x2.device)
         _lib.call("shg_attn_sublayer_bwd", _ADDR(L), E.run_addr(dtc), B, Sq, Sk, x2.data_ptr(), None, _ptr(mem2), saved.data_ptr(),
                   dy2.data_ptr(), _ptr(dx), None, _ptr(dmem), 0, scratch.data_ptr(), sid)
-        _keep_for_side_stream(x2, mem2, saved, scratch)
-        _note_grads(P.trainable)
+        E.after_backward_call((x2, mem2, saved, scratch), P.trainable)
         return (dx.view(B, Sq, H) if dx is not None else None), (dmem.view(B, Sk, H) if dmem is not None else None), None, None, None, None
 
 
@@ -1075,8 +1055,7 @@ class _DecoderStack(torch.autograd.Function):
         scratch = _bytes(_lib.lib().shg_decoder_scratch_bytes(n, dtc, B, Q, S, D.heads, D.ffn_dim), mem2.device)
         _lib.call("shg_decoder_bwd", _ADDR(arr), n, E.run_addr(dtc), B, Q, S, D.ffn_dim, _ptr(tgt2), mem2.data_ptr(), qp2.data_ptr(),
                   saved.data_ptr(), d2.data_ptr(), _ptr(dtgt), _ptr(dpos), _ptr(dmem), scratch.data_ptr(), sid)
-        _keep_for_side_stream(mem2, qp2, tgt2, saved, scratch)
-        _note_grads(D.trainable)
+        E.after_backward_call((mem2, qp2, tgt2, saved, scratch), D.trainable)
         return ((dmem.view(B, S, H) if dmem is not None else None), (dpos.view(B, Q, H) if dpos is not None else None),
                 (dtgt.view(B, Q, H) if dtgt is not None else None), None, None, None)
 

@@ -45,6 +45,9 @@ def build_parser():
     p.add_argument("--backbone", type=str, default="slow_r50")
     p.add_argument("--multiGPU", action="store_const", default=False, const=True)
     p.add_argument("--numWorkers", dest="num_workers", default=8, type=int)
+    p.add_argument("--novelComp", dest="novel_comp", action="store_const", default=False, const=True)
+    p.add_argument("--indirectRef", dest="indirect_ref", action="store_const", default=False, const=True)
+    p.add_argument("--compSteps", dest="comp_steps", action="store_const", default=False, const=True)
     # additions of this build
     p.add_argument("--computeDtype", dest="compute_dtype", default="bf16", choices=["bf16", "fp32"])
     return p

@@ -67,6 +67,7 @@ def _grads_after_backward(tr, b):
     out["total"].backward()
     if tr.world is not None:
         tr.world.finish()
+    E.join_side_streams()                      # (also issues weight gradients still queued for a grouped launch)
     torch.cuda.synchronize()
     return E.grad_arena.clone(), float(out["rel_ce"]), float(out["act_ce"])
 

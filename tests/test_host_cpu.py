@@ -233,3 +233,58 @@ def test_bench_constants_follow_the_survey_flop_table():
     # per-layer formulas of the same table: BertLayer(S) = S (4 H^2 + 2 H F) + 2 S^2 H MAC with H = 768, F = 3072
     layer = lambda S: 2.0 * (S * (4 * 768 ** 2 + 2 * 768 * 3072) + 2 * S * S * 768) / 1e9
     assert abs(5 * layer(40) - 2.856) < 2e-3 and abs(5 * layer(393) - 30.188) < 2e-3
+
+
+def test_agqa_evaluator_categories_follow_the_reference_order_and_arithmetic():
+    """agqa_data.py:363-700 / :702-883 / :886-1098: per-category accuracy = correct answers of the category / its questions, in
+    the order the reference's __main__ prints by position; checked on a hand-countable annotation set."""
+    import math
+    import types
+    from shg_vqa_amd.agqa_eval import ALL_QTYPES, INDIRECT, NOVEL_COMP, AGQAEvaluator
+    vocab = {"yes": 0, "no": 1, "cup": 2, "sit": 3}
+    D = {
+        1: dict(answer="yes", ans_type="binary", **{"global": ["obj-rel", "exists"]}, semantic="object", structural="verify",
+                nc_seq=1, nc_sup=0, nc_dur=0, nc_objrel=0, i_obj=1, i_act=0, i_temp=0, indirect=0, direct_equiv=None),
+        2: dict(answer="cup", ans_type="open", **{"global": ["obj-rel"]}, semantic="object", structural="query",
+                nc_seq=0, nc_sup=0, nc_dur=0, nc_objrel=1, i_obj=1, i_act=1, i_temp=0, indirect=1, direct_equiv=1),
+        3: dict(answer="sit", ans_type="open", **{"global": ["action-recognition", "sequencing"]}, semantic="action",
+                structural="query", nc_seq=1, nc_sup=0, nc_dur=0, nc_objrel=0, i_obj=0, i_act=1, i_temp=1, indirect=1, direct_equiv=9),
+        4: dict(answer="no", ans_type="binary", **{"global": ["superlative"]}, semantic="relation", structural="compare",
+                nc_seq=0, nc_sup=1, nc_dur=0, nc_objrel=0, i_obj=0, i_act=0, i_temp=0, indirect=1, direct_equiv=3),
+    }
+    ev = AGQAEvaluator(types.SimpleNamespace(id2datum=D, answerVocab=vocab))
+    pred = {1: 0, 2: 3, 3: 3, 4: 0}                    # correct: 1, 3; wrong: 2, 4
+    assert ev.evaluateOverall(pred) == 0.5
+    r = dict(zip([n for n, _ in ALL_QTYPES], ev.evaluateAllQtypes(pred)))
+    assert len(ALL_QTYPES) == 31 and [n for n, _ in ALL_QTYPES][:4] == ["overall", "binary", "open", "object-relationship"]
+    assert r["overall"] == 0.5 and r["binary"] == 0.5 and r["open"] == 0.5
+    assert r["object-relationship"] == 0.5 and r["object-relationship binary"] == 1.0 and r["object-relationship open"] == 0.0
+    assert r["exists"] == 1.0 and r["sequencing"] == 1.0 and r["sequencing open"] == 1.0 and math.isnan(r["sequencing binary"])
+    assert r["superlative"] == 0.0 and r["action-recognition"] == 1.0 and math.isnan(r["relationship-action"])
+    assert r["object"] == 0.5 and r["relationship"] == 0.0 and r["action"] == 1.0 and r["query"] == 0.5 and r["verify"] == 1.0
+    nc = dict(zip([n for n, _ in NOVEL_COMP], ev.evaluateNovelComp(pred)))
+    assert len(NOVEL_COMP) == 15 and nc["sequencing"] == 1.0 and nc["superlative"] == 0.0 and nc["object relationship open"] == 0.0
+    assert ev.evaluateCompSteps(pred) == [0.5, 0.5, 0.5]
+    recall, pq = ev.evaluateIndirectRef(pred)
+    rc = dict(zip([n for n, _ in INDIRECT], recall))
+    assert rc["object"] == 0.5 and rc["action"] == 0.5 and rc["localization"] == 1.0
+    # precision set: indirect questions whose DIRECT equivalent (in the split) was answered correctly: 2 (<- 1 correct), 4 (<- 3 correct)
+    assert sorted(q["answer"] for q in pq) == ["cup", "no"]
+    pr = dict(zip([n for n, _ in INDIRECT], ev.evaluatePrecision(pq)))
+    assert pr["object"] == 0.0 and pr["action"] == 0.0 and math.isnan(pr["localization"])
+    # the ground truth scores 1.0 everywhere a category is populated
+    truth = {q: vocab[d["answer"]] for q, d in D.items()}
+    assert all(v == 1.0 or math.isnan(v) for v in ev.evaluateAllQtypes(truth))
+
+
+def test_synthetic_split_carries_evaluator_annotations_and_the_cli_parses_the_reference_flags():
+    from shg_vqa_amd.agqa_hgqa import AGQA, get_tuple
+    from shg_vqa_amd.param import parse_args
+    t = get_tuple("valid", 4, n=12)
+    assert AGQA.oracle_score(t) == 1.0
+    q2a = {i: t.dataset.answer_index(i) for i in range(12)}
+    assert t.evaluator.evaluateAllQtypes(q2a)[0] == 1.0
+    it = t.dataset[5]
+    assert int(it["target"].argmax()) == t.dataset.answer_index(5)
+    a = parse_args(["--taskHGQA", "--noCaps", "--LossHGPerFrame", "--test", "valid,test", "--indirectRef", "--multiGPU", "--load", "x"])
+    assert a.indirect_ref and a.multiGPU and a.test == "valid,test" and not a.novel_comp

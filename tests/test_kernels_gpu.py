@@ -951,3 +951,39 @@ def test_matcher_forward_rejects_class_ids_outside_the_logits():
         m({"pred_logits": logits}, [{"labels": [torch.tensor([1, 5]), torch.tensor([2])]}])
     with pytest.raises(ValueError):
         m({"pred_logits": logits}, [{"labels": [torch.tensor([1, 2, 3, 4, 1]), torch.tensor([2])]}])
+
+
+def test_wgrad_group_is_exact_on_integer_data_and_handles_mixed_problem_lists(K):
+    """shg_wgrad_group: the weight gradients of several layers in one grid of 256 x 256 tiles (the eight of a decoder layer here,
+    with their real shapes), ragged row counts falling back to the plain GEMM, accumulation into a running fp32 sum; small
+    integers make every sum exact, so a tile computed twice, never, or with another problem's operands shows."""
+    gen = torch.Generator().manual_seed(5)
+
+    def prob(rows, n_out, n_in, ld_extra=0):
+        dyb = torch.randint(-2, 3, (rows, n_out + ld_extra), generator=gen).float().to(DEV).bfloat16()
+        xb = torch.randint(-2, 3, (rows, n_in), generator=gen).float().to(DEV).bfloat16()
+        dy = dyb[:, :n_out]
+        gw = torch.randint(-3, 4, (n_out, n_in), generator=gen).float().to(DEV)
+        return dy, xb, gw
+
+    shapes = [(4096, 1536, 768, 768), (4096, 768, 768, 0), (4096, 768, 768, 0), (4096, 768, 768, 0), (12576, 1536, 768, 0),
+              (4096, 768, 768, 0), (4096, 2048, 768, 0), (4096, 768, 2048, 0), (1536, 768, 768, 0), (1280, 3072, 768, 0),
+              (5664, 768, 768, 0), (128, 264, 72, 0)]
+    probs = [prob(*s_) for s_ in shapes]
+    ref = [gw + dy.float().t() @ x.float() for dy, x, gw in probs]
+    K.wgrad_group(probs)
+    torch.cuda.synchronize()
+    for i, ((dy, x, gw), r) in enumerate(zip(probs, ref)):
+        assert torch.equal(gw, r), (i, shapes[i], (gw - r).abs().max().item())
+    # a small group: split along the rows, partial tiles meet through fp32 atomics (integers: still exact)
+    small = [prob(4096, 768, 768), prob(4096, 1536, 768)]
+    ref = [gw + dy.float().t() @ x.float() for dy, x, gw in small]
+    K.wgrad_group(small)
+    for (dy, x, gw), r in zip(small, ref):
+        assert torch.equal(gw, r)
+    # fp32 operands: the fallback path
+    f32 = [(dy.float(), x.float(), gw.clone()) for dy, x, gw in probs[:3]]
+    ref = [gw + dy.t() @ x for dy, x, gw in f32]
+    K.wgrad_group(f32)
+    for (dy, x, gw), r in zip(f32, ref):
+        assert torch.equal(gw, r)
