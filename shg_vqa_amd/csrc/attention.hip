@@ -1,20 +1,35 @@
 // Fused multi-head attention (head dim 64) for gfx950: forward, dQ and dK/dV kernels.
 //
 // Layout idea: every product is arranged so that the softmax row lives on a LANE.
-//   forward, per wave 16 queries:   S^T = K . Q^T   (keys on accumulator rows, query = lane & 15)
-//                                   O^T = V^T . P^T (P^T taken straight from the S^T accumulators)
+//   forward, per wave 16 * NB queries:  S^T = K . Q^T   (keys on accumulator rows, query = lane & 15)
+//                                       O^T = V^T . P^T (P^T taken straight from the S^T accumulators)
 // The running max / sum / rescale of the online softmax are therefore lane-local (two xor-shuffles
 // join the four 16-lane groups), P never goes through LDS, and V^T is read from the row-major V
 // tile with the transposing LDS read.  K and V tiles (64 keys x 64) are staged in LDS once per
-// workgroup (4 waves = 64 queries), double-buffered: the next tile streams global -> LDS directly
+// workgroup (4 waves), double-buffered: the next tile streams global -> LDS directly
 // (global_load_lds, XOR swizzle on the source address) while the current one feeds the MFMAs.
 // The [B,H,Sq,Sk] score tensor of the reference (modeling_capsbert.py:394-418) is never formed.
 //
+// What bounds these kernels is the softmax arithmetic, not the matrix cores (a 393 x 393 head is 77 M score
+// elements per launch against 15 GFLOP of MFMA work: ~8 us of matrix time, ~20 us of VALU time at one exponential
+// per element), so the second version of the kernels is built around the VALU budget per score element:
+//   * scores live in the log2 domain: t = s * (scale * log2 e) + mask * log2 e is ONE fma, p = exp2(t - m) one
+//     subtraction and one v_exp_f32 (the natural exponential costs an extra multiply per element);
+//   * a wave owns NB = 2 blocks of 16 queries (forward, dQ) or keys (dK/dV): every K / V / Q / dO fragment read
+//     from LDS feeds two MFMAs, a workgroup covers 128 rows per barrier pair instead of 64, and the key-tile loop
+//     runs half as often per query;
+//   * the additive key mask of the BERT blocks is staged in LDS with the key tile (one 4-byte direct-to-LDS load per
+//     lane) instead of one global load per score element; the tail test (key >= Sk) only exists in the last tile;
+//   * the output accumulators are only rescaled when some running maximum actually moved (wave-uniform test).
+//
 // Backward recomputes P from the saved log-sum-exp:
-//   dQ kernel  (per wave 16 queries, loops over key tiles):   dS^T = P^T o (dP^T - delta),  dQ^T = K^T . dS^T
-//   dKV kernel (per wave 16 keys, loops over query tiles):     dV^T = dO^T . P,  dK^T = Q^T . dS
+//   dQ kernel  (per wave 16 NB queries, loops over key tiles):   dS^T = P^T o (dP^T - delta),  dQ^T = K^T . dS^T
+//   dKV kernel (per wave 16 NB keys, loops over query tiles):     dV^T = dO^T . P,  dK^T = Q^T . dS
 // Both are deterministic (no atomics).
 #include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "mma.h"
 
@@ -32,214 +47,327 @@ struct AttnParams {
     uint64_t stream_id;
 };
 
-template <int MASK>
-__device__ __forceinline__ float mask_value(const float* mask, int b, int qrow, int key, int Sk) {
-    if (MASK == SHG_MASK_KEY) return mask[(int64_t)b * Sk + key];
-    if (MASK == SHG_MASK_FULL) return mask[(int64_t)qrow * Sk + key];
-    return 0.f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// 64 floats (one per lane of ONE wave) global -> LDS, clamped at n - 1
+__device__ __forceinline__ void load_row64_async(char* lds, const float* src, int first, int n, int lane) {
+    const int i = min(first + lane, n - 1);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + i), (lds_ptr_t)lds, 4, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MASK>
+// LDS per stage: K tile, V tile, 64 mask floats (MASK_KEY)
+template <typename T> constexpr int fwd_stage_bytes() { return 2 * Tile64<T>::BYTES + 256; }
+
+template <typename T, int MASK, int NB, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restrict__ o, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
-    // two stages of (K tile, V tile): the next key tile streams into LDS while this one is consumed
+    constexpr int STG = fwd_stage_bytes<T>();
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int b = blockIdx.z, h = blockIdx.y;
-    const int qidx = blockIdx.x * 64 + wave * 16 + li;
-    const int qrow = min(qidx, P.Sq - 1);
-    const T* qptr = (const T*)P.q + (int64_t)b * P.q_bs + (int64_t)qrow * P.q_ss + h * 64;
     const T* kbase = (const T*)P.k + (int64_t)b * P.k_bs + h * 64;
     const T* vbase = (const T*)P.v + (int64_t)b * P.v_bs + h * 64;
-    load_tile64_async<T>(smem, kbase, P.k_ss, min(64, P.Sk), tid);
-    load_tile64_async<T>(smem + TL::BYTES, vbase, P.v_ss, min(64, P.Sk), tid);
-    const Frag<T> qf0 = glb_row_frag(qptr, 0, g), qf1 = glb_row_frag(qptr, 32, g);
-    const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
-    const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)((P.Sk + 1) & ~1);   // even row pitch
-
-    f32x4 acc_o[4];
+    const float* mrow = (MASK == SHG_MASK_KEY) ? P.mask + (int64_t)b * P.Sk : nullptr;
+    auto stage = [&](int buf, int kb) {
+        char* base = smem + buf * STG;
+        const int valid = min(64, P.Sk - kb);
+        load_tile64_async<T>(base, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
+        load_tile64_async<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
+        if (MASK == SHG_MASK_KEY && wave_u == 0) load_row64_async(base + 2 * TL::BYTES, mrow, kb, P.Sk, lane);
+    };
+    stage(0, 0);
+    int qidx[NB], qrow[NB];
+    Frag<T> qf[NB][2];
+    uint64_t drop_row[NB];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) acc_o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int n = 0; n < NB; ++n) {
+        qidx[n] = blockIdx.x * (64 * NB) + wave * (16 * NB) + 16 * n + li;
+        qrow[n] = min(qidx[n], P.Sq - 1);
+        const T* qptr = (const T*)P.q + (int64_t)b * P.q_bs + (int64_t)qrow[n] * P.q_ss + h * 64;
+        qf[n][0] = glb_row_frag(qptr, 0, g);
+        qf[n][1] = glb_row_frag(qptr, 32, g);
+        drop_row[n] = ((uint64_t)(b * P.H + h) * P.Sq + qrow[n]) * (uint64_t)((P.Sk + 1) & ~1);   // even row pitch
+    }
+    const uint64_t seed = DROP ? dropout_seed(P.seed_state, P.stream_id) : 0;
+    const float c2 = P.scale * LOG2E;
+    // a wave whose rows all lie past the end only helps staging the tiles (wave-uniform; it keeps every barrier)
+    const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sq;
+
+    f32x4 acc_o[NB][4];
+    float m_run[NB], l_run[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        m_run[n] = -INFINITY;
+        l_run[n] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc_o[n][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
 
     for (int kb = 0; kb < P.Sk; kb += 64) {
-        const char* ldsK = smem + cur * 2 * TL::BYTES;
+        const char* ldsK = smem + cur * STG;
         const char* ldsV = ldsK + TL::BYTES;
-        if (kb + 64 < P.Sk) {
-            char* nxt = smem + (cur ^ 1) * 2 * TL::BYTES;
-            const int valid = min(64, P.Sk - kb - 64);
-            load_tile64_async<T>(nxt, kbase + (int64_t)(kb + 64) * P.k_ss, P.k_ss, valid, tid);
-            load_tile64_async<T>(nxt + TL::BYTES, vbase + (int64_t)(kb + 64) * P.v_ss, P.v_ss, valid, tid);
-        }
+        const float* ldsM = reinterpret_cast<const float*>(ldsK + 2 * TL::BYTES);
+        if (kb + 64 < P.Sk) stage(cur ^ 1, kb + 64);
 
-        f32x4 s[4];
+        if (active) {
+        f32x4 s[NB][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma(s[kt], lds_row_frag<T>(ldsK, 16 * kt + li, 0, g), qf0);
-            mma(s[kt], lds_row_frag<T>(ldsK, 16 * kt + li, 32, g), qf1);
+            const Frag<T> kf0 = lds_row_frag<T>(ldsK, 16 * kt + li, 0, g), kf1 = lds_row_frag<T>(ldsK, 16 * kt + li, 32, g);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                s[n][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma(s[n][kt], kf0, qf[n][0]);
+                mma(s[n][kt], kf1, qf[n][1]);
+            }
         }
-        float mx = -INFINITY;
+        // log2-domain scores: t = s * scale * log2(e) + mask * log2(e).  The tail test only exists in the last key tile
+        // (TAIL is a compile-time constant inside `softmax`: per-element run-time tests would become per-element branches).
+        f32x4 mk[4];
+        if (MASK == SHG_MASK_KEY) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt) mk[kt] = *reinterpret_cast<const f32x4*>(ldsM + 16 * kt + 4 * g) * LOG2E;
+        }
+        bool moved = false;
+        float alpha[NB];
+        auto softmax = [&](auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb + 16 * kt + 4 * g + r;
-                float val = s[kt][r] * P.scale;
-                if (MASK != SHG_MASK_NONE) val += mask_value<MASK>(P.mask, b, qrow, min(key, P.Sk - 1), P.Sk);
-                if (key >= P.Sk) val = -INFINITY;
-                s[kt][r] = val;
-                mx = fmaxf(mx, val);
+            for (int n = 0; n < NB; ++n) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t;
+                        if (MASK == SHG_MASK_KEY) t = fmaf(s[n][kt][r], c2, mk[kt][r]);
+                        else if (MASK == SHG_MASK_FULL)
+                            t = fmaf(s[n][kt][r], c2, P.mask[(int64_t)qrow[n] * P.Sk + min(kb + 16 * kt + 4 * g + r, P.Sk - 1)] * LOG2E);
+                        else t = s[n][kt][r] * c2;
+                        if (TAIL) t = (kb + 16 * kt + 4 * g + r >= P.Sk) ? -INFINITY : t;
+                        s[n][kt][r] = t;
+                        mx = fmaxf(mx, t);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[n], mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                alpha[n] = fast_exp2(m_run[n] - m_use);
+                moved = moved || (m_new != m_run[n]);
+                float rs = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float p = fast_exp2(s[n][kt][r] - m_use);
+                        rs += p;
+                        if (DROP)
+                            p = dropout_keep_run(seed, (drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? p * P.drop_scale : 0.f;
+                        s[n][kt][r] = p;
+                    }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[n] = l_run[n] * alpha[n] + rs;
+                m_run[n] = m_new;
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_use);
-        float rs = 0.f;
+        };
+        if (kb + 64 > P.Sk) softmax(std::true_type{}); else softmax(std::false_type{});
+        if (__builtin_amdgcn_ballot_w64(moved)) {       // some running maximum moved: rescale the output accumulators
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int n = 0; n < NB; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __expf(s[kt][r] - m_use);
-                rs += p;
-                if (P.drop_thr) {
-                    const int key = kb + 16 * kt + 4 * g + r;
-                    p = dropout_keep_run(seed, (drop_row + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? p * P.drop_scale : 0.f;
-                }
-                s[kt][r] = p;
-            }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) acc_o[d] *= alpha;
+                for (int d = 0; d < 4; ++d) acc_o[n][d] *= alpha[n];
+        }
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
-            const Frag<T> pf = acc_frag<T>(s[2 * sx], s[2 * sx + 1]);
+            Frag<T> pf[NB];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) mma(acc_o[d], lds_col_frag<T>(ldsV, 32 * sx, 16 * d, lane), pf);
+            for (int n = 0; n < NB; ++n) pf[n] = acc_frag<T>(s[n][2 * sx], s[n][2 * sx + 1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const Frag<T> vf = lds_col_frag<T>(ldsV, 32 * sx, 16 * d, lane);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) mma(acc_o[n][d], vf, pf[n]);
+            }
         }
+        }   // active
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
-    if (qidx < P.Sq) {
-        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        T* optr = o + ((int64_t)b * P.Sq + qidx) * (P.H * 64) + h * 64;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+    for (int n = 0; n < NB; ++n) {
+        if (qidx[n] < P.Sq) {
+            const float inv = l_run[n] > 0.f ? 1.f / l_run[n] : 0.f;
+            T* optr = o + ((int64_t)b * P.Sq + qidx[n]) * (P.H * 64) + h * 64;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) optr[16 * d + 4 * g + r] = from_f32<T>(acc_o[d][r] * inv);
-        if (g == 0) lse[((int64_t)b * P.H + h) * P.Sq + qidx] = m_run + logf(l_run);
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) optr[16 * d + 4 * g + r] = from_f32<T>(acc_o[n][d][r] * inv);
+            if (g == 0) lse[((int64_t)b * P.H + h) * P.Sq + qidx[n]] = (m_run[n] + log2f(l_run[n])) * LN2;      // natural log
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, dQ (also produces delta = rowsum(dO o O))
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MASK>
+template <typename T, int MASK, int NB, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T* __restrict__ o, const T* __restrict__ d_o,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           T* __restrict__ dq, int64_t dq_bs, int64_t dq_ss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
+    constexpr int STG = fwd_stage_bytes<T>();
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int b = blockIdx.z, h = blockIdx.y;
-    const int qidx = blockIdx.x * 64 + wave * 16 + li;
-    const int qrow = min(qidx, P.Sq - 1);
-    const T* qptr = (const T*)P.q + (int64_t)b * P.q_bs + (int64_t)qrow * P.q_ss + h * 64;
-    const int64_t orow = ((int64_t)b * P.Sq + qrow) * (P.H * 64) + h * 64;
     const T* kbase = (const T*)P.k + (int64_t)b * P.k_bs + h * 64;
     const T* vbase = (const T*)P.v + (int64_t)b * P.v_bs + h * 64;
-    const Frag<T> qf0 = glb_row_frag(qptr, 0, g), qf1 = glb_row_frag(qptr, 32, g);
-    const Frag<T> df0 = glb_row_frag(d_o + orow, 0, g), df1 = glb_row_frag(d_o + orow, 32, g);
-    const int64_t stat = ((int64_t)b * P.H + h) * P.Sq + qrow;
-    float dl = 0.f;
-    {
+    const float* mrow = (MASK == SHG_MASK_KEY) ? P.mask + (int64_t)b * P.Sk : nullptr;
+    int qidx[NB], qrow[NB];
+    Frag<T> qf[NB][2], df[NB][2];
+    float dl[NB], lse2[NB];
+    uint64_t drop_row[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        qidx[n] = blockIdx.x * (64 * NB) + wave * (16 * NB) + 16 * n + li;
+        qrow[n] = min(qidx[n], P.Sq - 1);
+        const T* qptr = (const T*)P.q + (int64_t)b * P.q_bs + (int64_t)qrow[n] * P.q_ss + h * 64;
+        const int64_t orow = ((int64_t)b * P.Sq + qrow[n]) * (P.H * 64) + h * 64;
+        qf[n][0] = glb_row_frag(qptr, 0, g);
+        qf[n][1] = glb_row_frag(qptr, 32, g);
+        df[n][0] = glb_row_frag(d_o + orow, 0, g);
+        df[n][1] = glb_row_frag(d_o + orow, 32, g);
         const Frag<T> of0 = glb_row_frag(o + orow, 0, g), of1 = glb_row_frag(o + orow, 32, g);
+        float d = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dl += to_f32(of0.v[j]) * to_f32(df0.v[j]) + to_f32(of1.v[j]) * to_f32(df1.v[j]);
-        dl += __shfl_xor(dl, 16, 64);
-        dl += __shfl_xor(dl, 32, 64);
-        if (g == 0 && qidx < P.Sq) delta[stat] = dl;
+        for (int j = 0; j < 8; ++j) d += to_f32(of0.v[j]) * to_f32(df[n][0].v[j]) + to_f32(of1.v[j]) * to_f32(df[n][1].v[j]);
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        const int64_t stat = ((int64_t)b * P.H + h) * P.Sq + qrow[n];
+        if (g == 0 && qidx[n] < P.Sq) delta[stat] = d;
+        dl[n] = d;
+        lse2[n] = lse[stat] * LOG2E;
+        drop_row[n] = ((uint64_t)(b * P.H + h) * P.Sq + qrow[n]) * (uint64_t)((P.Sk + 1) & ~1);
     }
-    const float lse_q = lse[stat];
-    const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
-    const uint64_t drop_row = ((uint64_t)(b * P.H + h) * P.Sq + qrow) * (uint64_t)((P.Sk + 1) & ~1);   // even row pitch
+    const uint64_t seed = DROP ? dropout_seed(P.seed_state, P.stream_id) : 0;
+    const float c2 = P.scale * LOG2E;
+    const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sq;       // wave-uniform, see the forward kernel
 
-    f32x4 acc[4];
+    f32x4 acc[NB][4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) acc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[n][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int buf, int kb) {
+        char* base = smem + buf * STG;
+        const int valid = min(64, P.Sk - kb);
+        load_tile64_async<T>(base, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
+        load_tile64_async<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
+        if (MASK == SHG_MASK_KEY && wave_u == 0) load_row64_async(base + 2 * TL::BYTES, mrow, kb, P.Sk, lane);
+    };
     // (all ordinary global loads above are consumed before the first direct-to-LDS load is issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    load_tile64_async<T>(smem, kbase, P.k_ss, min(64, P.Sk), tid);
-    load_tile64_async<T>(smem + TL::BYTES, vbase, P.v_ss, min(64, P.Sk), tid);
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
 
     for (int kb = 0; kb < P.Sk; kb += 64) {
-        const char* ldsK = smem + cur * 2 * TL::BYTES;
+        const char* ldsK = smem + cur * STG;
         const char* ldsV = ldsK + TL::BYTES;
-        if (kb + 64 < P.Sk) {
-            char* nxt = smem + (cur ^ 1) * 2 * TL::BYTES;
-            const int valid = min(64, P.Sk - kb - 64);
-            load_tile64_async<T>(nxt, kbase + (int64_t)(kb + 64) * P.k_ss, P.k_ss, valid, tid);
-            load_tile64_async<T>(nxt + TL::BYTES, vbase + (int64_t)(kb + 64) * P.v_ss, P.v_ss, valid, tid);
-        }
-        f32x4 s[4], dp[4];
+        const float* ldsM = reinterpret_cast<const float*>(ldsK + 2 * TL::BYTES);
+        if (kb + 64 < P.Sk) stage(cur ^ 1, kb + 64);
+        if (active) {
+        f32x4 s[NB][4], dp[NB][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma(s[kt], lds_row_frag<T>(ldsK, 16 * kt + li, 0, g), qf0);
-            mma(s[kt], lds_row_frag<T>(ldsK, 16 * kt + li, 32, g), qf1);
-            mma(dp[kt], lds_row_frag<T>(ldsV, 16 * kt + li, 0, g), df0);
-            mma(dp[kt], lds_row_frag<T>(ldsV, 16 * kt + li, 32, g), df1);
-        }
+            const Frag<T> kf0 = lds_row_frag<T>(ldsK, 16 * kt + li, 0, g), kf1 = lds_row_frag<T>(ldsK, 16 * kt + li, 32, g);
+            const Frag<T> vf0 = lds_row_frag<T>(ldsV, 16 * kt + li, 0, g), vf1 = lds_row_frag<T>(ldsV, 16 * kt + li, 32, g);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb + 16 * kt + 4 * g + r;
-                float val = s[kt][r] * P.scale;
-                if (MASK != SHG_MASK_NONE) val += mask_value<MASK>(P.mask, b, qrow, min(key, P.Sk - 1), P.Sk);
-                float p = (key < P.Sk) ? __expf(val - lse_q) : 0.f;
-                float dpe = dp[kt][r];
-                if (P.drop_thr) dpe = dropout_keep_run(seed, (drop_row + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? dpe * P.drop_scale : 0.f;
-                s[kt][r] = p * (dpe - dl);
+            for (int n = 0; n < NB; ++n) {
+                s[n][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[n][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma(s[n][kt], kf0, qf[n][0]);
+                mma(s[n][kt], kf1, qf[n][1]);
+                mma(dp[n][kt], vf0, df[n][0]);
+                mma(dp[n][kt], vf1, df[n][1]);
             }
+        }
+        f32x4 mk[4];
+        if (MASK == SHG_MASK_KEY) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) mk[kt] = *reinterpret_cast<const f32x4*>(ldsM + 16 * kt + 4 * g) * LOG2E;
+        }
+        auto elems = [&](auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t;
+                        if (MASK == SHG_MASK_KEY) t = fmaf(s[n][kt][r], c2, mk[kt][r]);
+                        else if (MASK == SHG_MASK_FULL)
+                            t = fmaf(s[n][kt][r], c2, P.mask[(int64_t)qrow[n] * P.Sk + min(kb + 16 * kt + 4 * g + r, P.Sk - 1)] * LOG2E);
+                        else t = s[n][kt][r] * c2;
+                        float p = fast_exp2(t - lse2[n]);
+                        if (TAIL) p = (kb + 16 * kt + 4 * g + r >= P.Sk) ? 0.f : p;
+                        float dpe = dp[n][kt][r];
+                        if (DROP)
+                            dpe = dropout_keep_run(seed, (drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? dpe * P.drop_scale : 0.f;
+                        s[n][kt][r] = p * (dpe - dl[n]);
+                    }
+        };
+        if (kb + 64 > P.Sk) elems(std::true_type{}); else elems(std::false_type{});
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
-            const Frag<T> dsf = acc_frag<T>(s[2 * sx], s[2 * sx + 1]);
+            Frag<T> dsf[NB];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) mma(acc[d], lds_col_frag<T>(ldsK, 32 * sx, 16 * d, lane), dsf);
+            for (int n = 0; n < NB; ++n) dsf[n] = acc_frag<T>(s[n][2 * sx], s[n][2 * sx + 1]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const Frag<T> kc = lds_col_frag<T>(ldsK, 32 * sx, 16 * d, lane);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) mma(acc[n][d], kc, dsf[n]);
+            }
         }
+        }   // active
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
-    if (qidx < P.Sq) {
-        T* out = dq + (int64_t)b * dq_bs + (int64_t)qidx * dq_ss + h * 64;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+    for (int n = 0; n < NB; ++n) {
+        if (qidx[n] < P.Sq) {
+            T* out = dq + (int64_t)b * dq_bs + (int64_t)qidx[n] * dq_ss + h * 64;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[16 * d + 4 * g + r] = from_f32<T>(acc[d][r] * P.scale);
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[16 * d + 4 * g + r] = from_f32<T>(acc[n][d][r] * P.scale);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, dK and dV
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MASK>
+template <typename T, int MASK, int NB, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T* __restrict__ d_o,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            T* __restrict__ dk, int64_t dk_bs, int64_t dk_ss,
@@ -250,35 +378,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
     constexpr int STG = 2 * TL::BYTES + 512;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int kidx = blockIdx.x * 64 + wave * 16 + li;
-    const int krow = min(kidx, P.Sk - 1);
-    const T* kptr = (const T*)P.k + (int64_t)b * P.k_bs + (int64_t)krow * P.k_ss + h * 64;
-    const T* vptr = (const T*)P.v + (int64_t)b * P.v_bs + (int64_t)krow * P.v_ss + h * 64;
-    const Frag<T> kf0 = glb_row_frag(kptr, 0, g), kf1 = glb_row_frag(kptr, 32, g);
-    const Frag<T> vf0 = glb_row_frag(vptr, 0, g), vf1 = glb_row_frag(vptr, 32, g);
+    int kidx[NB], krow[NB];
+    Frag<T> kf[NB][2], vf[NB][2];
+    float kmask2[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        kidx[n] = blockIdx.x * (64 * NB) + wave * (16 * NB) + 16 * n + li;
+        krow[n] = min(kidx[n], P.Sk - 1);
+        const T* kptr = (const T*)P.k + (int64_t)b * P.k_bs + (int64_t)krow[n] * P.k_ss + h * 64;
+        const T* vptr = (const T*)P.v + (int64_t)b * P.v_bs + (int64_t)krow[n] * P.v_ss + h * 64;
+        kf[n][0] = glb_row_frag(kptr, 0, g);
+        kf[n][1] = glb_row_frag(kptr, 32, g);
+        vf[n][0] = glb_row_frag(vptr, 0, g);
+        vf[n][1] = glb_row_frag(vptr, 32, g);
+        kmask2[n] = (MASK == SHG_MASK_KEY) ? P.mask[(int64_t)b * P.Sk + krow[n]] * LOG2E : 0.f;
+    }
     const T* qbase = (const T*)P.q + (int64_t)b * P.q_bs + h * 64;
     const T* dbase = d_o + (int64_t)b * P.Sq * (P.H * 64) + h * 64;
     const int64_t stat0 = ((int64_t)b * P.H + h) * P.Sq;
-    const uint64_t seed = P.drop_thr ? dropout_seed(P.seed_state, P.stream_id) : 0;
+    const uint64_t seed = DROP ? dropout_seed(P.seed_state, P.stream_id) : 0;
     const uint64_t drop_bh = (uint64_t)(b * P.H + h) * P.Sq;
-    const float kmask = (MASK == SHG_MASK_KEY) ? P.mask[(int64_t)b * P.Sk + krow] : 0.f;
+    const float c2 = P.scale * LOG2E;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sk;       // wave-uniform, see the forward kernel
+    const bool key_tail = (int)(blockIdx.x * (64 * NB) + (wave_u + 1) * (16 * NB)) > P.Sk;   // this wave holds keys past Sk
     auto stage = [&](int buf, int qb) {
         char* base = smem + buf * STG;
         const int valid = min(64, P.Sq - qb);
         load_tile64_async<T>(base, qbase + (int64_t)qb * P.q_ss, P.q_ss, valid, tid);
         load_tile64_async<T>(base + TL::BYTES, dbase + (int64_t)qb * (P.H * 64), P.H * 64, valid, tid);
         // per-query statistics: 64 floats each, one 4-byte direct-to-LDS load per lane (waves 0 and 1)
-        const int qq = min(qb + lane, P.Sq - 1);
-        if (wave_u == 0) __builtin_amdgcn_global_load_lds((glb_ptr)(lse + stat0 + qq), (lds_ptr)(base + 2 * TL::BYTES), 4, 0, 0);
-        if (wave_u == 1) __builtin_amdgcn_global_load_lds((glb_ptr)(delta + stat0 + qq), (lds_ptr)(base + 2 * TL::BYTES + 256), 4, 0, 0);
+        if (wave_u == 0) load_row64_async(base + 2 * TL::BYTES, lse + stat0, qb, P.Sq, lane);
+        if (wave_u == 1) load_row64_async(base + 2 * TL::BYTES + 256, delta + stat0, qb, P.Sq, lane);
     };
 
-    f32x4 acc_k[4], acc_v[4];
+    f32x4 acc_k[NB][4], acc_v[NB][4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) { acc_k[d] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_v[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { acc_k[n][d] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_v[n][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the register loads above are complete
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -291,61 +429,93 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
         const float* ldsLse = reinterpret_cast<const float*>(ldsQ + 2 * TL::BYTES);
         const float* ldsDelta = ldsLse + 64;
         if (qb + 64 < P.Sq) stage(cur ^ 1, qb + 64);
-        f32x4 s[4], dp[4];
+        if (active) {
+        f32x4 s[NB][4], dp[NB][4];
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
-            s[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma(s[qt], lds_row_frag<T>(ldsQ, 16 * qt + li, 0, g), kf0);
-            mma(s[qt], lds_row_frag<T>(ldsQ, 16 * qt + li, 32, g), kf1);
-            mma(dp[qt], lds_row_frag<T>(ldsD, 16 * qt + li, 0, g), vf0);
-            mma(dp[qt], lds_row_frag<T>(ldsD, 16 * qt + li, 32, g), vf1);
-        }
-        // lane: key = li (kidx), query = qb + 16 qt + 4 g + r
+            const Frag<T> qf0 = lds_row_frag<T>(ldsQ, 16 * qt + li, 0, g), qf1 = lds_row_frag<T>(ldsQ, 16 * qt + li, 32, g);
+            const Frag<T> df0 = lds_row_frag<T>(ldsD, 16 * qt + li, 0, g), df1 = lds_row_frag<T>(ldsD, 16 * qt + li, 32, g);
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = 16 * qt + 4 * g + r;
-                const int query = qb + ql;
-                float val = s[qt][r] * P.scale;
-                if (MASK == SHG_MASK_KEY) val += kmask;
-                if (MASK == SHG_MASK_FULL) val += P.mask[(int64_t)min(query, P.Sq - 1) * P.Sk + krow];
-                float p = (query < P.Sq && kidx < P.Sk) ? __expf(val - ldsLse[ql]) : 0.f;
-                float dpe = dp[qt][r];
-                float pd = p;
-                if (P.drop_thr) {
-                    const bool keep = dropout_keep(seed, (drop_bh + (uint64_t)min(query, P.Sq - 1)) * (uint64_t)((P.Sk + 1) & ~1) + (uint64_t)krow, P.drop_thr);
-                    dpe = keep ? dpe * P.drop_scale : 0.f;
-                    pd = keep ? p * P.drop_scale : 0.f;
-                }
-                s[qt][r] = p * (dpe - ldsDelta[ql]);   // dS
-                dp[qt][r] = pd;                        // dropped P
+            for (int n = 0; n < NB; ++n) {
+                s[n][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[n][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma(s[n][qt], qf0, kf[n][0]);
+                mma(s[n][qt], qf1, kf[n][1]);
+                mma(dp[n][qt], df0, vf[n][0]);
+                mma(dp[n][qt], df1, vf[n][1]);
             }
+        }
+        // lane: key = li of block n, query = qb + 16 qt + 4 g + r
+        f32x4 l2[4], dlt[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            l2[qt] = *reinterpret_cast<const f32x4*>(ldsLse + 16 * qt + 4 * g) * LOG2E;
+            dlt[qt] = *reinterpret_cast<const f32x4*>(ldsDelta + 16 * qt + 4 * g);
+        }
+        auto elems = [&](auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;     // last query tile, or a key block that reaches past Sk
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int query = qb + 16 * qt + 4 * g + r;
+                        float t;
+                        if (MASK == SHG_MASK_KEY) t = fmaf(s[n][qt][r], c2, kmask2[n]);
+                        else if (MASK == SHG_MASK_FULL)
+                            t = fmaf(s[n][qt][r], c2, P.mask[(int64_t)min(query, P.Sq - 1) * P.Sk + krow[n]] * LOG2E);
+                        else t = s[n][qt][r] * c2;
+                        float p = fast_exp2(t - l2[qt][r]);
+                        if (TAIL) p = (query >= P.Sq || kidx[n] >= P.Sk) ? 0.f : p;
+                        float dpe = dp[n][qt][r];
+                        float pd = p;
+                        if (DROP) {
+                            const bool keep = dropout_keep(seed, (drop_bh + (uint64_t)min(query, P.Sq - 1)) * (uint64_t)((P.Sk + 1) & ~1) + (uint64_t)krow[n], P.drop_thr);
+                            dpe = keep ? dpe * P.drop_scale : 0.f;
+                            pd = keep ? p * P.drop_scale : 0.f;
+                        }
+                        s[n][qt][r] = p * (dpe - dlt[qt][r]);   // dS
+                        dp[n][qt][r] = pd;                       // dropped P
+                    }
+        };
+        if (qb + 64 > P.Sq || key_tail) elems(std::true_type{}); else elems(std::false_type{});
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) {
-            const Frag<T> pf = acc_frag<T>(dp[2 * sx], dp[2 * sx + 1]);
-            const Frag<T> dsf = acc_frag<T>(s[2 * sx], s[2 * sx + 1]);
+            Frag<T> pf[NB], dsf[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                pf[n] = acc_frag<T>(dp[n][2 * sx], dp[n][2 * sx + 1]);
+                dsf[n] = acc_frag<T>(s[n][2 * sx], s[n][2 * sx + 1]);
+            }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                mma(acc_v[d], lds_col_frag<T>(ldsD, 32 * sx, 16 * d, lane), pf);
-                mma(acc_k[d], lds_col_frag<T>(ldsQ, 32 * sx, 16 * d, lane), dsf);
+                const Frag<T> dc = lds_col_frag<T>(ldsD, 32 * sx, 16 * d, lane), qc = lds_col_frag<T>(ldsQ, 32 * sx, 16 * d, lane);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    mma(acc_v[n][d], dc, pf[n]);
+                    mma(acc_k[n][d], qc, dsf[n]);
+                }
             }
         }
+        }   // active
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
-    if (kidx < P.Sk) {
-        T* ok = dk + (int64_t)b * dk_bs + (int64_t)kidx * dk_ss + h * 64;
-        T* ov = dv + (int64_t)b * dv_bs + (int64_t)kidx * dv_ss + h * 64;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+    for (int n = 0; n < NB; ++n) {
+        if (kidx[n] < P.Sk) {
+            T* ok = dk + (int64_t)b * dk_bs + (int64_t)kidx[n] * dk_ss + h * 64;
+            T* ov = dv + (int64_t)b * dv_bs + (int64_t)kidx[n] * dv_ss + h * 64;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ok[16 * d + 4 * g + r] = from_f32<T>(acc_k[d][r] * P.scale);
-                ov[16 * d + 4 * g + r] = from_f32<T>(acc_v[d][r]);
-            }
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ok[16 * d + 4 * g + r] = from_f32<T>(acc_k[n][d][r] * P.scale);
+                    ov[16 * d + 4 * g + r] = from_f32<T>(acc_v[n][d][r]);
+                }
+        }
     }
 }
 
@@ -359,18 +529,39 @@ static int attn_check(const AttnParams& P, int dtype, int mask_kind, float p_dro
         return fail_arg("attention: q/k/v must be 16-byte aligned");
     if (mask_kind < 0 || mask_kind > 2 || (mask_kind != SHG_MASK_NONE && !P.mask)) return fail_arg("attention: bad mask");
     if (p_drop < 0.f || p_drop >= 1.f) return fail_arg("attention: bad p_drop");
+    if (p_drop > 0.f && !P.seed_state) return fail_arg("attention: dropout needs seed_state");
     return 0;
+}
+
+// rows per wave: two 16-row blocks once the row count fills a 128-row workgroup reasonably (393 rows: 4 workgroups
+// of 128 with 13 of 16 waves busy, against 7 workgroups of 64); short sequences (the 40-token questions, the 48 action
+// queries) keep one block so that more workgroups exist
+static int blocks_per_wave(int rows, int dtype) {
+    static const int nb = []() { const char* e = getenv("SHG_ATTN_NB"); return e ? atoi(e) : 2; }();
+    return (nb == 2 && dtype == SHG_BF16 && rows >= 96) ? 2 : 1;
 }
 
 }  // namespace shg
 
 using namespace shg;
 
-#define ATTN_DISPATCH(KERNEL, T, LDS, ...)                                                                        \
-    do {                                                                                                          \
-        if (mask_kind == SHG_MASK_NONE) hipLaunchKernelGGL((KERNEL<T, SHG_MASK_NONE>), grid, block, LDS, st, __VA_ARGS__); \
-        else if (mask_kind == SHG_MASK_KEY) hipLaunchKernelGGL((KERNEL<T, SHG_MASK_KEY>), grid, block, LDS, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<T, SHG_MASK_FULL>), grid, block, LDS, st, __VA_ARGS__);                   \
+// (more than 64 KiB of dynamic LDS - the fp32 parity instantiations - needs the per-function limit raised first)
+#define ATTN_LAUNCH(KERN, LDS, ...)                                                                                   \
+    do {                                                                                                              \
+        if ((LDS) > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+        hipLaunchKernelGGL(KERN, grid, block, LDS, st, __VA_ARGS__);                                                  \
+    } while (0)
+#define ATTN_DISPATCH_D(KERNEL, T, NB, D, LDS, ...)                                                                   \
+    do {                                                                                                              \
+        if (mask_kind == SHG_MASK_NONE) ATTN_LAUNCH((KERNEL<T, SHG_MASK_NONE, NB, D>), LDS, __VA_ARGS__);            \
+        else if (mask_kind == SHG_MASK_KEY) ATTN_LAUNCH((KERNEL<T, SHG_MASK_KEY, NB, D>), LDS, __VA_ARGS__);         \
+        else ATTN_LAUNCH((KERNEL<T, SHG_MASK_FULL, NB, D>), LDS, __VA_ARGS__);                                       \
+    } while (0)
+// (the dropout test is a template parameter: a run-time test per score element turns into a branch per element)
+#define ATTN_DISPATCH(KERNEL, T, NB, LDS, ...)                                                                        \
+    do {                                                                                                              \
+        if (P.drop_thr) ATTN_DISPATCH_D(KERNEL, T, NB, true, LDS, __VA_ARGS__);                                       \
+        else ATTN_DISPATCH_D(KERNEL, T, NB, false, LDS, __VA_ARGS__);                                                 \
     } while (0)
 
 extern "C" int shg_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B,
@@ -383,9 +574,13 @@ extern "C" int shg_attention_fwd(const void* q, const void* k, const void* v, vo
     if (int e = attn_check(P, dtype, mask_kind, p_drop)) return e;
     if (!o || !lse) return fail_arg("attention_fwd: null output");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((Sq + 63) / 64, H, B), block(256);
-    if (dtype == SHG_F32) ATTN_DISPATCH(attn_fwd_kernel, float, 4 * Tile64<float>::BYTES, P, (float*)o, lse);
-    else ATTN_DISPATCH(attn_fwd_kernel, bf16_t, 4 * Tile64<bf16_t>::BYTES, P, (bf16_t*)o, lse);
+    // two query blocks per wave pay when nothing but the softmax competes for registers (no dropout: the inference /
+    // forward-only pass, 54 -> 49 us at 393 x 393); with the mask hash in the loop one block keeps three waves per SIMD
+    const int nb = (p_drop > 0.f || Sq < 256) ? 1 : blocks_per_wave(Sq, dtype);
+    dim3 grid((Sq + 64 * nb - 1) / (64 * nb), H, B), block(256);
+    if (dtype == SHG_F32) ATTN_DISPATCH(attn_fwd_kernel, float, 1, 2 * fwd_stage_bytes<float>(), P, (float*)o, lse);
+    else if (nb == 2) ATTN_DISPATCH(attn_fwd_kernel, bf16_t, 2, 2 * fwd_stage_bytes<bf16_t>(), P, (bf16_t*)o, lse);
+    else ATTN_DISPATCH(attn_fwd_kernel, bf16_t, 1, 2 * fwd_stage_bytes<bf16_t>(), P, (bf16_t*)o, lse);
     return check_launch("attention_fwd");
 }
 
@@ -403,18 +598,26 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256);
     {
-        dim3 grid((Sq + 63) / 64, H, B);
+        static const int nb_dq = []() { const char* e = getenv("SHG_ATTN_NB_DQ"); return e ? atoi(e) : 1; }();   // measured: 141 / 197 us (1) vs 144 / 203 us (2)
+        const int nb = nb_dq == 2 ? blocks_per_wave(Sq, dtype) : 1;
+        dim3 grid((Sq + 64 * nb - 1) / (64 * nb), H, B);
         if (dtype == SHG_F32)
-            ATTN_DISPATCH(attn_bwd_dq_kernel, float, 4 * Tile64<float>::BYTES, P, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, dq_bstride, dq_sstride);
+            ATTN_DISPATCH(attn_bwd_dq_kernel, float, 1, 2 * fwd_stage_bytes<float>(), P, (const float*)o, (const float*)d_o, lse, delta, (float*)dq, dq_bstride, dq_sstride);
+        else if (nb == 2)
+            ATTN_DISPATCH(attn_bwd_dq_kernel, bf16_t, 2, 2 * fwd_stage_bytes<bf16_t>(), P, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, dq_bstride, dq_sstride);
         else
-            ATTN_DISPATCH(attn_bwd_dq_kernel, bf16_t, 4 * Tile64<bf16_t>::BYTES, P, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, dq_bstride, dq_sstride);
+            ATTN_DISPATCH(attn_bwd_dq_kernel, bf16_t, 1, 2 * fwd_stage_bytes<bf16_t>(), P, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, dq_bstride, dq_sstride);
     }
     {
-        dim3 grid((Sk + 63) / 64, H, B);
+        static const int nb_dkv = []() { const char* e = getenv("SHG_ATTN_NB_DKV"); return e ? atoi(e) : 1; }();
+        const int nb = nb_dkv == 2 ? blocks_per_wave(Sk, dtype) : 1;
+        dim3 grid((Sk + 64 * nb - 1) / (64 * nb), H, B);
         if (dtype == SHG_F32)
-            ATTN_DISPATCH(attn_bwd_dkv_kernel, float, 2 * (2 * Tile64<float>::BYTES + 512), P, (const float*)d_o, lse, delta, (float*)dk, dk_bstride, dk_sstride, (float*)dv, dv_bstride, dv_sstride);
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, float, 1, 2 * (2 * Tile64<float>::BYTES + 512), P, (const float*)d_o, lse, delta, (float*)dk, dk_bstride, dk_sstride, (float*)dv, dv_bstride, dv_sstride);
+        else if (nb == 2)
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 2, 2 * (2 * Tile64<bf16_t>::BYTES + 512), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
         else
-            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 2 * (2 * Tile64<bf16_t>::BYTES + 512), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 1, 2 * (2 * Tile64<bf16_t>::BYTES + 512), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
     }
     return check_launch("attention_bwd");
 }

@@ -86,10 +86,13 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
-// random word of element pair `pair` (= element index >> 1); `seed` comes from dropout_seed()
+// random word of element pair `pair` (= element index >> 1); `seed` comes from dropout_seed().
+// 32-bit integer multiplies are quarter-rate instructions (16 cycles per wave, as much as the exponential of a softmax
+// element), so the counter goes into the hash by addition only: the two multiplies left are those of hash32 itself, which
+// avalanches consecutive counters on its own.  (The attention kernels spend as long on these masks as on the softmax.)
 __device__ __forceinline__ uint32_t dropout_pair_word(uint64_t seed, uint64_t pair) {
     const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
-    return hash32(lo * 0x9E3779B1u + (uint32_t)seed + hi * 0x85EBCA77u) ^ (uint32_t)(seed >> 32);
+    return hash32(lo + (uint32_t)seed + ((hi << 16) | (hi >> 16))) ^ (uint32_t)(seed >> 32);
 }
 __device__ __forceinline__ bool dropout_keep_word(uint32_t word, int odd, uint32_t threshold) {
     return ((word >> (odd ? 16 : 0)) & 0xFFFFu) >= (threshold >> 16);

@@ -25,7 +25,13 @@ struct ColsumJob {
     int64_t rows, cols, ld;
     float* out;
 };
+struct FinishJob {
+    const float* parts[3];
+    float* outs[3];
+    int n, n_part, cols;
+};
 struct Exec {
+    std::vector<FinishJob> fq;
     std::vector<hipEvent_t> events;
     size_t cursor = 0;
     // deferred weight gradients (shg_run_t.defer_wgrad): problems, bias column sums, and the streams their operands come from
@@ -82,6 +88,12 @@ static int fork_wgrad(const shg_run_t* R, void** out) {
     return 0;
 }
 
+static void note_producer(Exec* ex, void* stream) {
+    for (void* p : ex->producers)
+        if (p == stream) return;
+    ex->producers.push_back(stream);
+}
+
 // (shg_colsum_accumulate takes at most 512 16-byte chunks per row: wider outputs go in column slices)
 static int colsum_sliced(const void* dy, int dtype, int64_t rows, int64_t n_out, int64_t ldy, float* gb, void* st) {
     const int64_t es = esize(dtype), max_cols = 512 * (16 / es);
@@ -104,9 +116,7 @@ static int wgrad(const shg_run_t* R, const shg_linear_t& lin, const void* dy, in
             ex->pending_tiles += ((n_out + 255) / 256) * ((n_in + 255) / 256);
         }
         if (want_b) ex->cq.push_back(ColsumJob{dy, rows, n_out, ldy, lin.gb});
-        bool seen = false;
-        for (void* p : ex->producers) seen = seen || p == R->stream;
-        if (!seen) ex->producers.push_back(R->stream);
+        note_producer(ex, R->stream);
         return 0;
     }
     void* st = nullptr;
@@ -171,17 +181,27 @@ static int attn_args_ok(const shg_attn_sublayer_t* L, const shg_run_t* R, int B,
     return 0;
 }
 
-static int finish_ln_grads(const shg_norm_t& ln, float* g_bias, const float* parts, int n_part, int cols, void* st) {
-    const float* ps[3];
-    float* outs[3];
-    int n = 0;
+// LayerNorm gamma / beta (+ bias) gradients: second stage of the column sums.  Only the optimiser reads them, so the launch
+// goes to the weight-gradient stream (or its queue) and the dependent chain on the main stream does not wait for it.
+static int finish_ln_grads(const shg_run_t* R, const shg_norm_t& ln, float* g_bias, const float* parts, int n_part, int cols) {
+    FinishJob f{};
     if (ln.g_gamma) {
-        ps[n] = parts; outs[n++] = ln.g_gamma;
-        ps[n] = parts + (int64_t)n_part * cols; outs[n++] = ln.g_beta;
+        f.parts[f.n] = parts; f.outs[f.n++] = ln.g_gamma;
+        f.parts[f.n] = parts + (int64_t)n_part * cols; f.outs[f.n++] = ln.g_beta;
     }
-    if (g_bias) { ps[n] = parts + (int64_t)2 * n_part * cols; outs[n++] = g_bias; }
-    if (!n) return 0;
-    return shg_colsum_finish_multi(ps, outs, n, n_part, cols, st);
+    if (g_bias) { f.parts[f.n] = parts + (int64_t)2 * n_part * cols; f.outs[f.n++] = g_bias; }
+    if (!f.n) return 0;
+    f.n_part = n_part;
+    f.cols = cols;
+    if (R->defer_wgrad && R->wgrad_stream && R->exec) {
+        Exec* ex = reinterpret_cast<Exec*>(R->exec);
+        ex->fq.push_back(f);
+        note_producer(ex, R->stream);
+        return 0;
+    }
+    void* st = nullptr;
+    CK(fork_wgrad(R, &st));
+    return shg_colsum_finish_multi(f.parts, f.outs, f.n, f.n_part, f.cols, st);
 }
 
 static int attn_fwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int Sq, int Sk, const void* x, const void* xpos,
@@ -231,7 +251,7 @@ static int attn_bwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int
     CK(shg_bias_act_drop_res_ln_bwd(dy, s.z, nullptr, L->o.bias, L->ln.gamma, s.mean, s.rstd, w.dt, dx, w.parts,
                                     w.parts + (int64_t)w.n_part * H, dbi, w.n_part, dt, rq, (int)H, SHG_ACT_NONE, po, R->seed_state,
                                     sid + 1, st));
-    CK(finish_ln_grads(L->ln, L->o.gb, w.parts, w.n_part, (int)H, st));
+    CK(finish_ln_grads(R, L->ln, L->o.gb, w.parts, w.n_part, (int)H));
     CK(wgrad(R, L->o, w.dt, H, s.o, H, rq, H, H, false));
     CK(shg_gemm(w.dt, L->o.w, w.d_o, nullptr, dt, dt, rq, H, H, H, H, H, 1, 0, 0, st));
     if (mode == SHG_ATTN_SELF || mode == SHG_ATTN_DEC_SELF) {
@@ -338,7 +358,7 @@ static int ffn_bwd(const shg_ffn_sublayer_t* L, const shg_run_t* R, int64_t rows
     CK(shg_bias_act_drop_res_ln_bwd(dy, s.z, nullptr, L->l2.bias, L->ln.gamma, s.mean, s.rstd, w.dt, dx, w.parts,
                                     w.parts + (int64_t)w.n_part * H, dbi, w.n_part, dt, rows, H, SHG_ACT_NONE, po, R->seed_state, sid + 1,
                                     st));
-    CK(finish_ln_grads(L->ln, L->l2.gb, w.parts, w.n_part, H, st));
+    CK(finish_ln_grads(R, L->ln, L->l2.gb, w.parts, w.n_part, H));
     CK(wgrad(R, L->l2, w.dt, H, s.h, F, rows, H, F, false));
     // activation (and inner dropout) backward + linear1's bias gradient in the input-gradient GEMM's epilogue
     CK(shg_gemm_dact(w.dt, L->l2.w, w.dpre, s.pre, L->l1.gb, dt, rows, F, H, H, F, F, L->act, pi, R->seed_state, sid, st));
@@ -465,7 +485,7 @@ extern "C" int64_t shg_exec_pending_tiles(const shg_exec_t* h) {
 extern "C" int shg_exec_flush_wgrads(shg_exec_t* h, int dtype, void* wgrad_stream) {
     Exec* ex = reinterpret_cast<Exec*>(h);
     if (!ex) return fail_arg("exec_flush_wgrads: null handle");
-    if (ex->wq.empty() && ex->cq.empty()) return 0;
+    if (ex->wq.empty() && ex->cq.empty() && ex->fq.empty()) return 0;
     if (!wgrad_stream) return fail_arg("exec_flush_wgrads: deferred weight gradients need the weight-gradient stream");
     if (ex->events.empty()) return fail_arg("exec_flush_wgrads: shg_exec_t has no events");
     // sort: problems with equal row counts next to each other (a group shares its K length best), largest first
@@ -483,6 +503,11 @@ extern "C" int shg_exec_flush_wgrads(shg_exec_t* h, int dtype, void* wgrad_strea
         const ColsumJob& c = ex->cq[i];
         rc = colsum_sliced(c.x, dtype, c.rows, c.cols, c.ld, c.out, wgrad_stream);
     }
+    for (size_t i = 0; rc == 0 && i < ex->fq.size(); ++i) {
+        const FinishJob& f = ex->fq[i];
+        rc = shg_colsum_finish_multi(f.parts, f.outs, f.n, f.n_part, f.cols, wgrad_stream);
+    }
+    ex->fq.clear();
     ex->wq.clear();
     ex->cq.clear();
     ex->producers.clear();

@@ -54,10 +54,18 @@ template <typename T, int NTHR, bool KMAJ> __device__ __forceinline__ void chunk
 // operand sources
 // ---------------------------------------------------------------------------------------------
 // Plain matrix.  KMAJOR: stored [R][K] (row stride ld); otherwise stored [K][R].
+// 16 zero bytes in device memory: where the 8-phase kernel points the direct-to-LDS loads of K rows past the end of a
+// contraction-strided operand (ragged last K-tile of the grouped weight gradients)
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
 template <typename T, bool KMAJ> struct PlainSrc {
     static constexpr bool KMAJOR = KMAJ;
     const T* p;
     int64_t ld, r0, R, K;
+    // contraction-strided layout: K row (0..63) inside a K-tile that chunk i of this thread holds
+    __device__ __forceinline__ int k_row(int tid, int i, int nthr) const {
+        return ((tid + nthr * i) % (64 * Tile64<T>::CH)) / Tile64<T>::CH;
+    }
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void prefetch(int, int64_t) {}
     __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
@@ -921,7 +929,11 @@ __device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wr = wave_u >> 2, wc = wave_u & 3;
-    const int64_t nk_all = K / BK;
+    // K % 64 != 0 is supported for the form with BOTH operands contraction-strided plain matrices (weight gradients over a
+    // row count like 12 576 = 196 x 64 + 32): the loads of the last K-tile's rows past the end are pointed at 16 zero bytes
+    constexpr bool RAGGED_OK = !AK && !BKM && !SrcA::DYN && !SrcB::DYN;
+    const int64_t nk_all = RAGGED_OK ? (K + BK - 1) / BK : K / BK;
+    const int tail = RAGGED_OK ? (int)(K % BK) : 0;
     // grid_m < 0: walk M fastest instead (few row tiles, many column tiles - the weight-gradient shapes - so
     // that the tiles sharing a B column-panel sit next to each other)
     const int64_t n_tiles = SK ? (int64_t)sk.n_tiles : (int64_t)gx, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
@@ -980,13 +992,26 @@ __device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     // half-tile h of operand A / B of K-tile kt -> buffer buf (no-op past the end of the K range)
+    uint32_t bad_a = 0, bad_b = 0;                  // bit i: chunk i of this thread is a K row past the end in the ragged last K-tile
+    if constexpr (RAGGED_OK) {
+        if (tail) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bad_a |= (sa.k_row(tid, i, NTHR) >= tail ? 1u : 0u) << i;
+                bad_b |= (sb.k_row(tid, i, NTHR) >= tail ? 1u : 0u) << i;
+            }
+        }
+    }
     auto stage_a = [&](int buf, int h, int64_t kt) {
         if (kt >= nk) return;
         char* base = smem + buf * STAGE_BYTES + 64 * wave_u * 16;
+        const bool rag = RAGGED_OK && tail && (kb + kt) == nk_all - 1;          // wave-uniform
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * h + ii;
-            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(i, (kb + kt) * BK) + offa[i]), (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
+            const char* src = sa.k_base(i, (kb + kt) * BK) + offa[i];
+            if (rag && ((bad_a >> i) & 1u)) src = reinterpret_cast<const char*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
         }
     };
     auto stage_b = [&](int buf, int h, int64_t kt, uint32_t dyn) {
@@ -996,7 +1021,9 @@ __device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * h + ii;
             const uint32_t off = SrcB::DYN ? dyn : offb[i];
-            __builtin_amdgcn_global_load_lds((glb_ptr)(sb.k_base(i, (kb + kt) * BK) + off), (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
+            const char* src = sb.k_base(i, (kb + kt) * BK) + off;
+            if (RAGGED_OK && tail && (kb + kt) == nk_all - 1 && ((bad_b >> i) & 1u)) src = reinterpret_cast<const char*>(g_zero16);
+            __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
         }
     };
 
@@ -1463,14 +1490,15 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
     hipStream_t st = (hipStream_t)stream;
     using SA = PlainSrc<bf16_t, false>;
     using Grp = G8Group<float, SA, SA>;
-    static const int mode = []() { const char* e = getenv("SHG_WGRAD_GROUP"); return e ? atoi(e) : 1; }();
+    // SHG_WGRAD_GROUP: bit 0 grouped launches, bit 1 also for row counts that are not a multiple of 64 (ragged last K-tile)
+    static const int mode = []() { const char* e = getenv("SHG_WGRAD_GROUP"); return e ? atoi(e) : 3; }();
     int i = 0;
     while (i < n) {
         // take a run of problems the 8-phase kernel can do: bf16, whole 64-row K-tiles, 16-byte aligned rows
         int j = i;
         int64_t tiles = 0;
         auto ok8 = [&](const shg_wgrad_problem_t& q) {
-            return mode && dtype == SHG_BF16 && q.rows % BK == 0 && q.rows >= 2 * BK && q.n_out % 8 == 0 && q.n_in % 8 == 0 && q.ldy % 8 == 0 &&
+            return mode && dtype == SHG_BF16 && (q.rows % BK == 0 || (mode & 2)) && q.rows >= 2 * BK && q.n_out % 8 == 0 && q.n_in % 8 == 0 && q.ldy % 8 == 0 &&
                    q.ldx % 8 == 0 && al16(q.dy) && al16(q.x) && al16(q.gw) && q.n_in % 4 == 0 &&
                    (int64_t)BK * q.ldy * 2 < ((int64_t)1 << 32) && (int64_t)BK * q.ldx * 2 < ((int64_t)1 << 32);
         };
@@ -1486,13 +1514,17 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
                 const shg_wgrad_problem_t& q = probs[k];
                 if (!q.dy || !q.x || !q.gw || q.rows <= 0 || q.n_out <= 0 || q.n_in <= 0) return fail_arg("wgrad_group: bad problem");
                 G8Entry<float, SA, SA>& e = g.e[k - i];
-                const int64_t gm = (q.n_out + 255) / 256, gn = (q.n_in + 255) / 256, nk = q.rows / BK;
+                const int64_t gm = (q.n_out + 255) / 256, gn = (q.n_in + 255) / 256, nk = (q.rows + BK - 1) / BK;
                 // split-K only when the whole group cannot fill the chip: partial tiles meet in C through fp32 atomics
                 int split = 1;
                 if (tiles < 160) split = (int)std::max<int64_t>(1, std::min<int64_t>((224 + tiles - 1) / tiles, nk / 12));
+                // a weight applied more than once (the cross layers' shared modules, modeling_capsbert.py:1247-1249) has several
+                // problems adding into ONE gradient inside this grid: those add with atomics
+                bool shared = false;
+                for (int k2 = i; k2 < j; ++k2) shared = shared || (k2 != k && probs[k2].gw == q.gw);
                 e.sa = SA{(const bf16_t*)q.dy, q.ldy, 0, q.n_out, q.rows};
                 e.sb = SA{(const bf16_t*)q.x, q.ldx, 0, q.n_in, q.rows};
-                e.ep = Epilogue<float>{q.gw, q.n_in, nullptr, nullptr, SHG_ACT_NONE, 1, 1, nullptr, split > 1 ? 1 : 0};
+                e.ep = Epilogue<float>{q.gw, q.n_in, nullptr, nullptr, SHG_ACT_NONE, 1, 1, nullptr, (split > 1 || shared) ? 1 : 0};
                 e.M = q.n_out; e.N = q.n_in; e.K = q.rows;
                 e.grid_m = tile_order(gm, gn);
                 e.tiles = (int)(gm * gn);

@@ -981,6 +981,12 @@ def test_wgrad_group_is_exact_on_integer_data_and_handles_mixed_problem_lists(K)
     K.wgrad_group(small)
     for (dy, x, gw), r in zip(small, ref):
         assert torch.equal(gw, r)
+    # a weight that is applied twice (the shared cross layer) has two problems adding into ONE gradient inside the grid
+    a, b = prob(5664, 3072, 768), prob(5664, 3072, 768)
+    c = prob(5664, 768, 768)
+    ref = a[2] + a[0].float().t() @ a[1].float() + b[0].float().t() @ b[1].float()
+    K.wgrad_group([a, c, (b[0], b[1], a[2])])
+    assert torch.equal(a[2], ref), (a[2] - ref).abs().max()
     # fp32 operands: the fallback path
     f32 = [(dy.float(), x.float(), gw.clone()) for dy, x, gw in probs[:3]]
     ref = [gw + dy.t() @ x for dy, x, gw in f32]
