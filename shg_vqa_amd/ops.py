@@ -466,6 +466,9 @@ class _VisualConvTokens(torch.autograd.Function):
         x_cl, y1p, pre1, pre2 = ctx.saved_tensors
         w1, b1, w2, b2, cls_token, pe = ctx.params
         E = engine()
+        # the relation layers' last weight gradients are still queued for a grouped launch: issue them now, so that they drain
+        # beside the convolutions' backward instead of behind it (everything below fills the chip and ends the step)
+        E.flush_native_wgrads()
         B, n_tok, C = d_out.shape
         g32 = d_out.float()
         if pe._shg_grad is not None:
