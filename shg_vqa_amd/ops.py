@@ -418,9 +418,25 @@ def conv1_forward(feat, w1, b1, bufs=None):
     else:
         B, C, T, H, W = feat.shape
     if bufs is None:
-        bufs = (torch.zeros((B, T, H + 2, W + 2, C), dtype=cdt, device=feat.device),
-                torch.zeros((B, T - 4, H + 2, W + 2, w1.shape[0]), dtype=cdt, device=feat.device),
-                torch.empty((B, T - 4, H, W, w1.shape[0]), dtype=cdt, device=feat.device))
+        # the two zero-bordered buffers (170 MB + 47 MB at B = 32) are kept across steps: the kernels only ever write their
+        # interiors, so the borders stay zero and a step does not pay for zero-filling them again.  A step's backward has
+        # read them before the next step's forward overwrites them (same stream); torch.no_grad() passes share them too.
+        key = (B, T, H, W, C, w1.shape[0], cdt, feat.device)
+        cache = E.__dict__.setdefault("_conv_bufs", {})
+        bufs = cache.get(key)
+        # (a forward whose backward has not run yet still owns them: a second forward in between gets fresh buffers)
+        busy = getattr(E, "_conv_bufs_busy", False)
+        if busy:
+            bufs = None
+        if bufs is None or torch.cuda.is_current_stream_capturing():
+            bufs = (torch.zeros((B, T, H + 2, W + 2, C), dtype=cdt, device=feat.device),
+                    torch.zeros((B, T - 4, H + 2, W + 2, w1.shape[0]), dtype=cdt, device=feat.device),
+                    torch.empty((B, T - 4, H, W, w1.shape[0]), dtype=cdt, device=feat.device))
+            if not torch.cuda.is_current_stream_capturing() and not busy:
+                cache.clear()                      # one shape at a time (a new batch size replaces the old buffers)
+                cache[key] = bufs
+        if torch.is_grad_enabled() and cache.get(key) is bufs:
+            E._conv_bufs_busy = True
     x_cl, y1p, pre1 = bufs
     if channels_last:
         x_cl[:, :, 1:-1, 1:-1].copy_(feat)                 # the zero border stays as allocated
@@ -469,13 +485,20 @@ class _VisualConvTokens(torch.autograd.Function):
         # the relation layers' last weight gradients are still queued for a grouped launch: issue them now, so that they drain
         # beside the convolutions' backward instead of behind it (everything below fills the chip and ends the step)
         E.flush_native_wgrads()
+        E._conv_bufs_busy = False                  # (conv1_forward: the persistent buffers are free again after this backward)
         B, n_tok, C = d_out.shape
-        g32 = d_out.float()
+        # position / cls-token gradients (sums over the batch) only feed the optimiser: on the weight-gradient stream,
+        # not in front of the convolutions' backward (the batch reduction alone is ~0.4 ms of the main chain otherwise)
+        with _WgradStream(d_out):
+            g32 = d_out.float()
+            if pe._shg_grad is not None:
+                pe._shg_grad[:n_tok].add_(g32.sum(0))
+            if cls_token._shg_grad is not None:
+                cls_token._shg_grad.view(-1).add_(g32[:, 0].sum(0))
+            del g32
         if pe._shg_grad is not None:
-            pe._shg_grad[:n_tok].add_(g32.sum(0))
             E.grad_written(pe)
         if cls_token._shg_grad is not None:
-            cls_token._shg_grad.view(-1).add_(g32[:, 0].sum(0))
             E.grad_written(cls_token)
         d_tok = d_out[:, 1:].contiguous().view(pre2.shape)
         # conv2: GELU', bias grad, weight grad, input grad
