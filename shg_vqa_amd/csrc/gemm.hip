@@ -917,9 +917,13 @@ __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_
 
 // (the body is a device function so that the plain launch and the grouped launch - many small problems, one grid - share it:
 //  bx / by = this workgroup's tile slot and split-K part inside ITS problem, gx / gy = that problem's tile and split counts)
+// SK: ONE stream-K segment (`seg` of this workgroup) per call; returns false when the workgroup has no such segment.  The
+// segment loop lives in gemm8_sk_kernel, which re-reads the kernel arguments from the kernarg segment for every segment:
+// with the loop in here every argument (three operand / epilogue structs) stayed live across the whole pipelined main loop
+// and 95 SGPRs + 48 VGPRs were spilled (196 B of scratch per lane).
 template <typename TC, typename SrcA, typename SrcB, bool SK = false>
-__device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, int grid_m, StreamK sk,
-                                           const int bx, const int by, const int gx, const int gy) {
+__device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, int grid_m, StreamK sk,
+                                           const int bx, const int by, const int gx, const int gy, const int seg = 0) {
     static_assert(!SrcA::DYN, "only the B operand may gather per K-tile");
     using T = bf16_t;
     using TL = Tile64<T>;
@@ -938,14 +942,13 @@ __device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     // that the tiles sharing a B column-panel sit next to each other)
     const int64_t n_tiles = SK ? (int64_t)sk.n_tiles : (int64_t)gx, gm_t = grid_m < 0 ? -grid_m : grid_m, gn_t = n_tiles / gm_t;
 
-#pragma nounroll
-    for (int seg = 0; seg < (SK ? 64 : 1); ++seg) {
+    {
     int64_t tile, kb, nk;
     if constexpr (SK) {
         int s_ = seg;
         asm volatile("" : "+s"(s_));
         const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
-        if (d.nk == 0) break;
+        if (d.nk == 0) return false;
         tile = d.tile; kb = d.kb; nk = d.nk;
     } else {
         const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = bx % 8;
@@ -954,7 +957,7 @@ __device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         const int64_t per_split = (nk_all + gy - 1) / gy;
         kb = (int64_t)by * per_split;
         nk = min(nk_all, kb + per_split) - kb;               // K-tiles of this workgroup, numbered 0 .. nk-1 below
-        if (nk <= 0) return;
+        if (nk <= 0) return false;
     }
     const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
     const int64_t m0 = bm * 256, n0 = bn * 256;
@@ -1156,7 +1159,8 @@ __device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
             __threadfence();
             __syncthreads();
             if (tid == 0) __hip_atomic_store(sk.flags + d.slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
+            __syncthreads();                             // the accumulators' LDS staging area is the next segment's operand buffer
+            return true;
         }
         // the tile's tail was computed by one or two tail workgroups of this XCD (lower block indices): add what they published.
         // ASSUMPTION this wait rests on: the hardware dispatches the workgroups of one launch in increasing block index, and a
@@ -1208,12 +1212,36 @@ __device__ __forceinline__ void gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     if (ep.csum) RowWriter<TC>::flush_csum(csum_carry, ep, n0 + 128 * half + 64 * (wc >> 1), N, lane);
     if constexpr (SK) __syncthreads();               // the staging area is the next segment's first operand buffer
     }
+    return true;
 }
 
 template <typename TC, typename SrcA, typename SrcB, bool SK = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
                                                     int grid_m, StreamK sk) {
-    gemm8_body<TC, SrcA, SrcB, SK>(sa, sb, ep, M, N, K, grid_m, sk, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+    static_assert(!SK, "stream-K launches go through gemm8_sk_kernel");
+    gemm8_body<TC, SrcA, SrcB, false>(sa, sb, ep, M, N, K, grid_m, sk, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+}
+
+// Stream-K launch: all arguments in ONE struct, read afresh from the kernarg segment (scalar loads through a pointer the
+// compiler cannot see through) at the top of every segment, so that nothing but the segment counter lives across a segment.
+template <typename TC, typename SrcA, typename SrcB> struct G8SkArgs {
+    SrcA sa;
+    SrcB sb;
+    Epilogue<TC> ep;
+    int64_t M, N, K;
+    int grid_m;
+    StreamK sk;
+};
+template <typename TC, typename SrcA, typename SrcB>
+__global__ __launch_bounds__(512) void gemm8_sk_kernel(G8SkArgs<TC, SrcA, SrcB> unused_by_name) {
+    typedef const __attribute__((address_space(4))) G8SkArgs<TC, SrcA, SrcB>* karg_ptr;
+#pragma nounroll
+    for (int seg = 0; seg < 64; ++seg) {
+        karg_ptr p = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        const G8SkArgs<TC, SrcA, SrcB> a = *p;
+        if (!gemm8_body<TC, SrcA, SrcB, true>(a.sa, a.sb, a.ep, a.M, a.N, a.K, a.grid_m, a.sk, (int)blockIdx.x, 0, (int)gridDim.x, 1, seg)) break;
+    }
 }
 
 // Grouped launch: up to G8_MAX_GROUP independent problems (the weight gradients of several layers, each far too small to
@@ -1295,14 +1323,14 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
             nk - per_wg >= 8 && tiles * nk < ((int64_t)1 << 23)) {             // (32-bit plan arithmetic: sigma R nk stays below 2^31)
             StreamK sk = streamk_view(streamk_ws);
             {
-                auto kern = gemm8_kernel<TC, SrcA, SrcB, true>;
+                auto kern = gemm8_sk_kernel<TC, SrcA, SrcB>;
                 static std::atomic<uint64_t> raised_sk{0};   // per instantiation, one bit per device
                 if (!lds_raised(raised_sk))
                     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 sk.n_tiles = (int)tiles;
                 sk.sigma = (int)sg;
                 g_streamk_launches.fetch_add(1, std::memory_order_relaxed);
-                hipLaunchKernelGGL(kern, dim3(STREAMK_WGS), dim3(512), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn), sk);
+                hipLaunchKernelGGL(kern, dim3(STREAMK_WGS), dim3(512), lds, st, G8SkArgs<TC, SrcA, SrcB>{sa, sb, ep, M, N, K, tile_order(gm, gn), sk});
                 return check_launch(what);
             }
         }
