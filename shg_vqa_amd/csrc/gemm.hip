@@ -1234,6 +1234,7 @@ template <typename TC, typename SrcA, typename SrcB> struct G8SkArgs {
 };
 template <typename TC, typename SrcA, typename SrcB>
 __global__ __launch_bounds__(512) void gemm8_sk_kernel(G8SkArgs<TC, SrcA, SrcB> unused_by_name) {
+#if defined(__HIP_DEVICE_COMPILE__)                   // (the host pass only needs the symbol: it cannot copy out of address space 4)
     typedef const __attribute__((address_space(4))) G8SkArgs<TC, SrcA, SrcB>* karg_ptr;
 #pragma nounroll
     for (int seg = 0; seg < 64; ++seg) {
@@ -1242,6 +1243,7 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(G8SkArgs<TC, SrcA, SrcB> 
         const G8SkArgs<TC, SrcA, SrcB> a = *p;
         if (!gemm8_body<TC, SrcA, SrcB, true>(a.sa, a.sb, a.ep, a.M, a.N, a.K, a.grid_m, a.sk, (int)blockIdx.x, 0, (int)gridDim.x, 1, seg)) break;
     }
+#endif
 }
 
 // Grouped launch: up to G8_MAX_GROUP independent problems (the weight gradients of several layers, each far too small to
