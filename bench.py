@@ -279,7 +279,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "execution": mode, "ranks_seen": ranks_seen,
                        "grad_wire": a.grad_wire if reducer is not None else None},
             "step_mfma_frac": round(qa / world * TRAIN_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"kernel": "gemm8_kernel<bf16, ConvRowSrc, PlainSrc, stream-K> (shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
+            "roofline": {"kernel": "gemm8_sk_kernel<bf16, ConvRowSrc, PlainSrc> (stream-K; shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_live": False,
                          "launch_ms": round(k_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs)},

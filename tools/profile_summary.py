@@ -4,7 +4,7 @@
                                                                    <prefix>_conv1_row.json (the conv1 forward launches ALONE)
     python tools/profile_summary.py pmc <fetch_dir> <write_dir> <mfma_dir|-> <out.json>   PMC passes -> bytes / busy cycles per conv1 launch
 
-conv1 forward = gemm8_kernel<bf16, ConvRowSrc, PlainSrc<true>, SK> launches longer than 1.5 ms (conv2 forward shares the
+conv1 forward = gemm8_sk_kernel<bf16, ConvRowSrc, PlainSrc<true>> (gemm8_kernel<..., SK = true> before r02_d) launches longer than 1.5 ms (conv2 forward shares the
 instantiation but runs ~0.55 ms)."""
 import csv, glob, json, os, shutil, sys
 
@@ -17,7 +17,7 @@ def _one(d, pat):
 
 
 def is_conv_fwd(name):
-    return "gemm8_kernel" in name and "ConvRowSrc" in name and "ConvWeightColSrc" not in name and "ConvColSrc" not in name
+    return "gemm8" in name and "ConvRowSrc" in name and "ConvWeightColSrc" not in name and "ConvColSrc" not in name
 
 
 def stats(d, prefix):
