@@ -179,6 +179,12 @@ def main():
                          "runtime serialises the side-stream branch: measured slower); auto = eager")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything native libraries print there (RCCL writes a version banner to stdout
+    # when the communicator is created) goes to stderr instead, until the line itself is printed
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -295,16 +301,19 @@ def main():
         fp32_wanted = world == 1 and mode == "eager" and a.dtype == "bf16" and not a.no_extras
     else:
         fp32_wanted, line = False, None
-    if dist.is_initialized():
-        dist.destroy_process_group()
     if fp32_wanted:
         # last: the child process needs the GPU memory this process still holds only partly (5.7 GB of arenas each)
         log("fp32 parity-mode steps (child process) ...")
         del trainer, model, batches
         torch.cuda.empty_cache()
         line["fp32_parity_mode"] = fp32_parity_mode(B)
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
     if rank == 0:
         print(json.dumps(line), flush=True)
+    os.dup2(2, 1)
+    if dist.is_initialized():
+        dist.destroy_process_group()
     return
 
 
