@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--overlap-update", action="store_true", help="overlap BertAdam's sweep with the next step's conv1")
     ap.add_argument("--force-ddp", action="store_true", help="use the gradient reducer / RCCL path even with one rank (testing)")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce (N > 1)")
+    ap.add_argument("--reducer-only", action="store_true", help="attach the gradient reducer's hooks without any collective (measures their host cost)")
     ap.add_argument("--exec", dest="exec_mode", default="auto", choices=["auto", "graph", "eager"],
                     help="eager: launch every kernel from Python (weight gradients overlap the input-gradient chain on a "
                          "side stream); graph: replay the step from a captured hipGraph (no launch overhead, but the "
@@ -192,20 +193,21 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1 or a.force_ddp:
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
-
     from shg_vqa_amd.agqa_hgqa import AGQA, DataTuple, SyntheticAGQA
     from shg_vqa_amd.agqa_model import AGQAModel
+    from shg_vqa_amd import ddp
     from shg_vqa_amd.ddp import GradReducer
     from shg_vqa_amd.engine import engine, reset_engine
     from shg_vqa_amd.param import hgqa_args
 
-    log("imports done; building model")
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     reset_engine(compute_dtype=cdt, device=dev, seed=9595 + rank)
+    if world > 1 or a.force_ddp:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
+        ddp.init_process_group(dev)            # the engine's streams take their hardware queues before RCCL creates its own
+
+    log("imports done; building model")
     args = hgqa_args(compute_dtype=a.dtype, batch_size=a.batch, lr=1e-5)
     torch.manual_seed(9595)                                   # identical --fromScratch initialisation on every rank
     model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=args)
@@ -213,7 +215,7 @@ def main():
     E = engine()
     # --force-ddp with one rank: the collectives run anyway (a 1-rank all-reduce is the identity)
     reducer = GradReducer(E.grad_arena, force_collectives=a.force_ddp,
-                          grad_dtype=torch.bfloat16 if a.grad_wire == "bf16" else None) if (world > 1 or a.force_ddp) else None
+                          grad_dtype=torch.bfloat16 if a.grad_wire == "bf16" else None) if (world > 1 or a.force_ddp or a.reducer_only) else None
     trainer = AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=1), [None] * 1000, None), model=model, t_total=10000,
                    world=reducer)
     log("model in HBM arenas (%d params, %d with gradients); building batches" % (E.n_total, E.n_active))

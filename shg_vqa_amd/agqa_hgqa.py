@@ -453,21 +453,21 @@ def main(argv=None):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(max(n, 1)), "--master-addr",
                "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), "-m", "shg_vqa_amd.agqa_hgqa"] + argv
         return subprocess.call(cmd)
-    world = None
-    if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
-        local = int(os.environ["LOCAL_RANK"])
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from .engine import reset_engine
     rank = int(os.environ.get("RANK", "0"))
+    multi = "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if multi:
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
     dev = torch.device("cuda", torch.cuda.current_device())
     reset_engine(compute_dtype=torch.bfloat16 if args.compute_dtype == "bf16" else torch.float32, device=dev, seed=args.seed + rank)
+    if multi:
+        from . import ddp
+        ddp.init_process_group(dev)                # (binds the engine's streams to the hardware queues before RCCL's)
     torch.manual_seed(args.seed)                   # identical --fromScratch initialisation on every rank
     train = get_tuple(args.train, args.batch_size, shuffle=True, drop_last=True, seed=1234 + rank)
     valid = get_tuple(args.valid, args.batch_size, shuffle=False, drop_last=False) if args.valid else None
     agqa = AGQA(args, train_tuple=train, valid_tuple=valid)
-    if "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if multi:
         from .ddp import GradReducer
         agqa.world = GradReducer(engine().grad_arena)
         engine().grad_ready_hook = agqa.world.on_grad

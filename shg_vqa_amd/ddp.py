@@ -14,10 +14,13 @@ Design for MI355X / xGMI:
     weights such as the twice-applied x-layer write twice) and CHECKED on every later step: a step
     that writes a bucket more or less often than the learning step raises instead of silently
     reducing a half-written slice;
-  * the collective of a bucket is ordered behind EVERY stream that may have written the bucket: the
-    stream that reported the last write, the step's main stream, the weight-gradient stream and the
-    model's branch streams (autograd runs a backward node on the stream of its forward, so the last
-    write of a bucket may come from a branch stream while an earlier one is still in flight on main);
+  * the collective of a bucket is issued on the weight-gradient stream (no fifth stream: the four streams of a step own
+    the four hardware queues, see init_process_group), behind one event per
+    stream that REPORTED a write into the bucket (autograd runs a backward node on the stream of its forward,
+    so the last write of a bucket may come from a branch stream while an earlier one is still in flight on
+    main); the executor's flush has already ordered the weight-gradient stream behind the producers of the
+    queued weight gradients.  Cross-stream events are kept few on purpose: a separate communication stream
+    ordered behind all four streams per bucket cost 3.5 ms per step on a single rank;
   * the weighted set losses are normalised by the GLOBAL sum of class weights (as DataParallel does,
     which computes the loss on the gathered batch): the two loss sums are all-reduced before the
     division, and the BCE term is scaled by 1/world, so the all-reduce is a plain SUM of gradients
@@ -43,6 +46,18 @@ class _AllReduceSums(torch.autograd.Function):
     def backward(ctx, g):
         # the loss is identical on every rank, so is g: d(global sum)/d(local sum) = 1
         return g
+
+
+def init_process_group(device, backend="nccl", **kw):
+    """torch.distributed.init_process_group for the data-parallel step: binds the engine's four streams to the hardware
+    queues FIRST (Engine.bind_streams), then creates the communicator eagerly on `device`.  The other order costs ~2.7 ms
+    per step on MI355X even with an idle communicator (its streams take hardware-queue slots, two of the step's streams
+    end up sharing one)."""
+    from .engine import engine
+    engine().bind_streams()
+    if backend == "nccl":
+        kw.setdefault("device_id", torch.device(device))
+    dist.init_process_group(backend, **kw)
 
 
 def param_aligned_bounds(n, per, spans=None):
@@ -93,6 +108,8 @@ class GradReducer:
         self.launch_order = []
         self.grad_dtype = grad_dtype
         self.staging = {}
+        self.writers = [dict() for _ in self.bounds]      # per bucket: streams that reported a write this step
+        self.in_burst, self.burst_events = False, {}
 
     @staticmethod
     def _engine_spans(n):
@@ -122,6 +139,7 @@ class GradReducer:
         self.launched = [False] * len(self.bounds)
         self.handles = []
         self.launch_order = []
+        self.writers = [dict() for _ in self.bounds]
         self.main_stream = torch.cuda.current_stream() if self.use_streams else None
 
     def _buckets_of(self, off, numel):
@@ -131,8 +149,11 @@ class GradReducer:
 
     def on_grad(self, off, numel):
         """Engine.grad_ready_hook: the gradient slice [off, off+numel) has just been written."""
+        cur = torch.cuda.current_stream() if self.use_streams else None
         for b in self._buckets_of(off, numel):
             self.counts[b] += 1
+            if cur is not None:
+                self.writers[b][cur.cuda_stream] = cur
             if self.expected is not None:
                 if self.counts[b] > self.expected[b]:
                     raise RuntimeError("GradReducer: bucket %d [%d, %d) was written %d times, the learning step wrote it %d times "
@@ -149,20 +170,34 @@ class GradReducer:
         if not self.active():
             return
         if self.use_streams:
-            cur = torch.cuda.current_stream()
-            self.comm_stream.wait_stream(cur)
-            if self.main_stream is not None and self.main_stream != cur:
-                self.comm_stream.wait_stream(self.main_stream)
-            for s_ in self.extra_streams():               # the weight-gradient stream and the model's branch streams
-                if s_ != cur:
-                    self.comm_stream.wait_stream(s_)
-            with torch.cuda.stream(self.comm_stream):
+            # The collective is issued on the weight-gradient stream W (most of a bucket is written there, and the executor's
+            # flush has already ordered W behind every stream that produced a queued operand; W has ~2 ms of work per step, so
+            # it has room for the communication), behind one event per stream that REPORTED a write into this bucket (bias /
+            # LayerNorm / embedding gradients written on the chain or a branch stream).  Cross-stream events are not free here:
+            # ordering a separate communication stream behind all four streams for every bucket (4 x 18 event records per step)
+            # cost 3.5 ms per step on ONE rank with no data moved - the decoders' backward segment doubled
+            # (tools/step_segments.py, SEG_DDP=1) - most of that turned out to be the hardware-queue collision described at
+            # init_process_group above, but the records stay limited to the streams that matter and are shared within a burst.
+            W = self._wgrad_stream()
+            for st in self.writers[b].values():
+                if st != W:
+                    ev = self.burst_events.get(st.cuda_stream) if self.in_burst else None
+                    if ev is None:
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        if self.in_burst:
+                            self.burst_events[st.cuda_stream] = ev
+                    W.wait_event(ev)
+            with torch.cuda.stream(W):
                 self._reduce(view, b)
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
 
     def _reduce(self, view, b):
+        """Runs on the weight-gradient stream, in stream order.  bf16 wire: cast - reduce - cast back."""
         if self.grad_dtype is None or self.grad_dtype == view.dtype:
+            # synchronous in STREAM terms (the weight-gradient stream waits for the collective, the host does not): with
+            # async_op=True handles the same one-rank step took 27.4 instead of 23.5 ms (c10d keeps polling the open works)
             dist.all_reduce(view, op=dist.ReduceOp.SUM)
             return
         buf = self.staging.get(b)
@@ -171,6 +206,20 @@ class GradReducer:
         buf.copy_(view)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         view.copy_(buf)
+
+    def _wgrad_stream(self):
+        try:
+            from .engine import engine
+            W = engine().wgrad_stream()
+        except Exception:
+            W = None
+        return W if W is not None else self.comm_stream
+
+    def burst(self, on):
+        """Engine.flush_native_wgrads brackets its notification loop with burst(True) / burst(False): no kernel is enqueued
+        between the notifications of one flush, so the buckets launched inside it share one event per writer stream."""
+        self.in_burst = bool(on)
+        self.burst_events = {}
 
     def finish(self):
         """After backward: reduce whatever is left, then make the compute stream wait for the collectives."""
@@ -188,9 +237,10 @@ class GradReducer:
             if not self.launched[b]:
                 self._launch(b)
         for h in self.handles:
-            h.wait()
+            if hasattr(h, "wait"):
+                h.wait()                             # (GPU tensors: the CURRENT stream waits for the collective, not the host)
         if self.use_streams and self.active():
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream())
         if self.expected is None:
             self.expected = list(self.counts)
 

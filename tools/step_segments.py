@@ -15,7 +15,15 @@ reset_engine(compute_dtype=torch.bfloat16, device=dev)
 args = hgqa_args(compute_dtype="bf16", batch_size=32)
 model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=args)
 model.to_engine(torch.bfloat16)
-tr = AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=1), [None] * 1000, None), model=model, t_total=10000)
+red = None
+if os.environ.get("SEG_DDP"):                      # forced single-rank collectives through the gradient reducer (RCCL)
+    import torch.distributed as dist
+    from shg_vqa_amd.ddp import GradReducer
+    os.dup2(2, 1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29521", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=dev)
+    red = GradReducer(engine().grad_arena, force_collectives=os.environ["SEG_DDP"] != "hooks")
+tr = AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=1), [None] * 1000, None), model=model, t_total=10000, world=red)
 batches = bench.synthetic_device_batches(2, 32, 1234, dev)
 marks = []
 
