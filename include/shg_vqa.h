@@ -289,6 +289,10 @@ int shg_cast_f32(const float* src, void* dst, int dtype, int64_t n, void* stream
  *   shg_add2_accumulate: acc1[i] += c[i];  acc2[i] = init2 ? c[i] : acc2[i] + c[i]   (acc1 may be NULL)
  * Sums are formed in fp32 and rounded once. */
 int shg_add(const void* a, const void* b, void* out, int dtype, int64_t n, void* stream);
+/* Token assembly of VisualFeatEncoder (modeling_capsbert.py:1053-1072): out [B, n_tok, C] (dtype) with
+ * out[b, 0] = cls + pos[0] and out[b, 1 + t] = tok[b, t] + pos[1 + t];  tok [B, n_tok - 1, C] (dtype), cls [C], pos [>= n_tok, C] fp32. */
+int shg_tokens_assemble(const void* tok, const float* cls, const float* pos, void* out, int dtype, int B, int n_tok, int C,
+                        void* stream);
 int shg_add2_accumulate(void* acc1, void* acc2, const void* c, int init2, int dtype, int64_t n, void* stream);
 
 /* shg_bias_act_drop_res_ln_fwd with a second output y_pos = y + pos (pos, y_pos [rows, cols] (dtype), both NULL or both set):

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "shg_add_i64": ([P, L, P], c_int),
     "shg_cast_f32": ([P, P, I, L, P], c_int),
     "shg_add": ([P, P, P, I, L, P], c_int),
+    "shg_tokens_assemble": ([P, P, P, P, I, I, I, I, P], c_int),
     "shg_add2_accumulate": ([P, P, P, I, I, L, P], c_int),
     "shg_bias_act_drop_res_ln_fwd_pos": ([P, P, P, P, P, P, P, P, P, P, P, I, L, I, I, F, F, P, U, P], c_int),
     "shg_exec_create": ([I], c_void_p),

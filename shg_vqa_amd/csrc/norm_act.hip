@@ -586,6 +586,48 @@ __global__ __launch_bounds__(256) void add2_kernel(T* __restrict__ acc1, T* __re
 }
 }  // namespace shg
 
+namespace shg {
+// out[b, 0, :] = cls + pos[0];  out[b, 1 + t, :] = tok[b, t, :] + pos[1 + t]   (fp32 sums, rounded once)
+template <typename T>
+__global__ __launch_bounds__(256) void tokens_assemble_kernel(const T* __restrict__ tok, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, T* __restrict__ out, int B, int n_tok, int C) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V;
+    const int64_t n_vec = (int64_t)B * n_tok * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * V;
+        const int64_t row = i / cv;
+        const int t = (int)(row % n_tok);
+        const int64_t b = row / n_tok;
+        Vec16<T> o;
+        if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) o.set(j, cls[c0 + j] + pos[c0 + j]);
+        } else {
+            const Vec16<T> x = load16(tok + (b * (n_tok - 1) + (t - 1)) * C + c0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) o.set(j, x.get(j) + pos[(int64_t)t * C + c0 + j]);
+        }
+        store16(out + row * C + c0, o);
+    }
+}
+}  // namespace shg
+
+extern "C" int shg_tokens_assemble(const void* tok, const float* cls, const float* pos, void* out, int dtype, int B, int n_tok,
+                                   int C, void* stream) {
+    if (!tok || !cls || !pos || !out) return fail_arg("tokens_assemble: null pointer");
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("tokens_assemble: bad dtype");
+    const int V = dtype == SHG_BF16 ? 8 : 4;
+    if (B < 1 || n_tok < 2 || C < V || C % V) return fail_arg("tokens_assemble: bad sizes");
+    if (!aligned16(tok) || !aligned16(out)) return fail_arg("tokens_assemble: pointers must be 16-byte aligned");
+    const int64_t n_vec = (int64_t)B * n_tok * (C / V);
+    dim3 grid((unsigned)std::min<int64_t>((n_vec + 255) / 256, 4096)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SHG_F32) hipLaunchKernelGGL(tokens_assemble_kernel<float>, grid, block, 0, st, (const float*)tok, cls, pos, (float*)out, B, n_tok, C);
+    else hipLaunchKernelGGL(tokens_assemble_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)tok, cls, pos, (bf16_t*)out, B, n_tok, C);
+    return check_launch("tokens_assemble");
+}
+
 extern "C" int shg_add(const void* a, const void* b, void* out, int dtype, int64_t n, void* stream) {
     if (!a || !b || !out) return fail_arg("add: null pointer");
     if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("add: bad dtype");

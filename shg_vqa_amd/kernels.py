@@ -343,6 +343,18 @@ def gemm(a, b, out, bias=None, a_kmajor=True, b_kmajor=True, accumulate=False):
     return out
 
 
+def tokens_assemble(tok, cls, pos, out=None):
+    """tok [B, T, C] (compute dtype), cls fp32 [C] (any shape with C elements), pos fp32 [>= T + 1, C] -> [B, T + 1, C]."""
+    _dev(tok, cls, pos, out)
+    B, T, C = tok.shape
+    _need(tok.is_contiguous() and cls.dtype == torch.float32 and cls.numel() == C and cls.is_contiguous(), "tok contiguous, cls fp32 [C]")
+    _need(pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == C and pos.numel() >= (T + 1) * C, "pos fp32 [>= T + 1, C]")
+    if out is None:
+        out = torch.empty((B, T + 1, C), dtype=tok.dtype, device=tok.device)
+    _lib.call("shg_tokens_assemble", tok.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), _dt(tok), B, T + 1, C, _stream())
+    return out
+
+
 def wgrad_group(problems):
     """problems: list of (dy [rows, n_out], x [rows, n_in], gw fp32 [n_out, n_in]); gw += dy^T x for each, grouped launches
     where the shapes allow (shg_wgrad_group)."""

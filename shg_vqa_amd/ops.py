@@ -467,12 +467,7 @@ class _VisualConvTokens(torch.autograd.Function):
         y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True)
         B = x_cl.shape[0]
         C = y2.shape[-1]
-        tok = y2.view(B, -1, C)
-        n_tok = tok.shape[1] + 1
-        out = torch.empty((B, n_tok, C), dtype=cdt, device=x_cl.device)
-        pos = pe._shg_store[:n_tok]
-        out[:, 0] = (cls_token._shg_store.view(1, C) + pos[0:1]).to(cdt)
-        out[:, 1:] = (tok.float() + pos[1:].unsqueeze(0)).to(cdt)
+        out = K.tokens_assemble(y2.view(B, -1, C), cls_token._shg_store.view(-1), pe._shg_store)     # cls + positions, one kernel
         ctx.save_for_backward(x_cl, y1p, pre1, pre2)
         ctx.params = (w1, b1, w2, b2, cls_token, pe)
         return out
