@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
     const T* dbase = d_o + (int64_t)b * P.Sq * (P.H * 64) + h * 64;
     const int64_t stat0 = ((int64_t)b * P.H + h) * P.Sq;
     const uint64_t seed = DROP ? dropout_seed(P.seed_state, P.stream_id) : 0;
-    const uint64_t drop_bh = (uint64_t)(b * P.H + h) * P.Sq;
+    const uint64_t drop_pitch = (uint64_t)((P.Sk + 1) & ~1);                       // even row pitch of the dropout counter
+    const bool odd_lane = (li & 1) != 0;
     const float c2 = P.scale * LOG2E;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sk;       // wave-uniform, see the forward kernel
@@ -430,6 +431,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
         const float* ldsDelta = ldsLse + 64;
         if (qb + 64 < P.Sq) stage(cur ^ 1, qb + 64);
         if (active) {
+        uint64_t drop_base[NB];                               // element index of (query qb + 4 g, key krow[n])
+        if (DROP) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                drop_base[n] = ((uint64_t)(b * P.H + h) * P.Sq + (uint64_t)(qb + 4 * g)) * drop_pitch + (uint64_t)krow[n];
+        }
         f32x4 s[NB][4], dp[NB][4];
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -457,7 +464,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt)
+                for (int qt = 0; qt < 4; ++qt) {
+                    // dropout words of this lane's four (query, key) elements.  Keys 2j and 2j + 1 (lanes li = 2j, 2j + 1)
+                    // share the word of a query row (dropout_pair_word: one hash per element PAIR, pairs run along the keys,
+                    // row pitch even): the even lane hashes the rows r = 0, 1, the odd lane r = 2, 3, and they swap.  The row
+                    // offset (16 qt + r) * pitch is wave-uniform (scalar unit), so a word costs two 64-bit adds and the hash -
+                    // the first version paid a 64-bit vector multiply and a hash per ELEMENT, more than the tile's MFMAs.
+                    // (Queries past Sq / keys past Sk give don't-care words: p is zeroed below.)
+                    uint32_t wd[4] = {0, 0, 0, 0};
+                    if (DROP) {
+                        const uint64_t e0 = drop_base[n] + (uint64_t)(16 * qt) * drop_pitch + (uint64_t)(odd_lane ? 2 : 0) * drop_pitch;
+                        const uint32_t mine0 = dropout_pair_word(seed, e0 >> 1), mine1 = dropout_pair_word(seed, (e0 + drop_pitch) >> 1);
+                        const uint32_t other0 = __shfl_xor(mine0, 1, 64), other1 = __shfl_xor(mine1, 1, 64);
+                        wd[0] = odd_lane ? other0 : mine0;
+                        wd[1] = odd_lane ? other1 : mine1;
+                        wd[2] = odd_lane ? mine0 : other0;
+                        wd[3] = odd_lane ? mine1 : other1;
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int query = qb + 16 * qt + 4 * g + r;
@@ -471,13 +494,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                         float dpe = dp[n][qt][r];
                         float pd = p;
                         if (DROP) {
-                            const bool keep = dropout_keep(seed, (drop_bh + (uint64_t)min(query, P.Sq - 1)) * (uint64_t)((P.Sk + 1) & ~1) + (uint64_t)krow[n], P.drop_thr);
+                            const bool keep = dropout_keep_word(wd[r], krow[n] & 1, P.drop_thr);
                             dpe = keep ? dpe * P.drop_scale : 0.f;
                             pd = keep ? p * P.drop_scale : 0.f;
                         }
                         s[n][qt][r] = p * (dpe - dlt[qt][r]);   // dS
                         dp[n][qt][r] = pd;                       // dropped P
                     }
+                }
         };
         if (qb + 64 > P.Sq || key_tail) elems(std::true_type{}); else elems(std::false_type{});
 #pragma unroll

@@ -1,12 +1,12 @@
 // Per-frame Hungarian matcher on the GPU (replaces lxrt/matcher.py:62-80 + scipy LSAP).
 //
-// One wave handles FRAMES_PER_WAVE frame-problems.  Phase 1 (all 64 lanes): for every query row of
-// the wave's frames, a wave-cooperative softmax (coalesced row read, shuffle reductions) and the
-// gather of the target columns -> cost = -softmax[q, tgt_j] (fp32) into LDS as float64.
-// Phase 2 (one lane per problem): the shortest-augmenting-path solver with SciPy's scan order and
-// tie rules in float64 on its LDS slice, so the indices are bit-identical to
-// scipy.optimize.linear_sum_assignment.  Problems are at most 8x8: latency-bound, not HBM-bound
-// (reads 4096 x 457 logits = 7.5 MB per call).
+// One wave per frame-problem.  Phase 1 (all 64 lanes): for every query row of the frame, a wave-cooperative
+// softmax (coalesced row read, shuffle reductions) and the gather of the target columns ->
+// cost = -softmax[q, tgt_j] (fp32) into LDS as float64.  Phase 2 (one lane): the shortest-augmenting-path
+// solver with SciPy's scan order and tie rules in float64 on the LDS copy, so the indices are bit-identical
+// to scipy.optimize.linear_sum_assignment.  Problems are at most 8x8: latency-bound, not HBM-bound
+// (reads 4096 x 457 logits = 7.5 MB per call), so the grid is one small wave per frame (512 waves at B = 32 -
+// eight frames per wave, as in round 1, left 192 of 256 CUs without work and took 183 us per call).
 #include <math.h>
 
 #include "common.h"
@@ -87,59 +87,84 @@ __device__ void emit_assignment(LsapScratch& s, int R, int n, bool transposed, i
             if (s.col4row[t] == q) { out_q[k] = q; out_t[k] = t; ++k; }
 }
 
-template <typename T>
+// One wave per frame.  NV > 0: the row has at most 64 NV classes and is held in NV registers per lane; the loop over the
+// frame's queries is fully unrolled, so the loads of all rows are in flight together (the kernel is latency-bound: 8 rows of
+// <= 1 KB per wave).  NV == 0: any class count, rows read twice.  Either way a lane adds its classes in increasing order and
+// the lane sums meet in the same butterfly, so both paths give the same bits.
+template <typename T, int NV>
 __global__ __launch_bounds__(64) void hungarian_per_frame_kernel(
     const T* __restrict__ logits, int n_frames, int R, int C, const int64_t* __restrict__ tgt,
     const int32_t* __restrict__ tgt_len, int64_t background, int64_t* __restrict__ out_q,
     int64_t* __restrict__ out_t, int64_t* __restrict__ out_grid) {
-    __shared__ LsapScratch scratch[FRAMES_PER_WAVE];
+    __shared__ LsapScratch s;
     const int lane = threadIdx.x;
-    const int f0 = blockIdx.x * FRAMES_PER_WAVE;
-
-    // phase 1: softmax statistics + gathered cost entries
-    for (int lf = 0; lf < FRAMES_PER_WAVE; ++lf) {
-        const int f = f0 + lf;
-        if (f >= n_frames) break;
-        const int n = min(max(tgt_len[f], 0), R);
-        if (n == 0) continue;
-        for (int q = 0; q < R; ++q) {
-            const T* row = logits + ((int64_t)f * R + q) * C;
-            float mx = -INFINITY;
-            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
-            mx = wave_max(mx);
-            float sum = 0.f;
-            for (int c = lane; c < C; c += 64) sum += expf(to_f32(row[c]) - mx);
-            sum = wave_sum(sum);
-            if (lane < n) {
-                // (a class id outside [0, C) is a caller error - the reference's out_prob[:, tgt_ids] raises IndexError,
-                // matcher.py:74; the host wrappers check it - here it is clamped so that the read stays inside the row)
-                const int64_t cls = min(max(tgt[(int64_t)f * R + lane], (int64_t)0), (int64_t)C - 1);
-                const float p = expf(to_f32(row[cls]) - mx) / sum;
-                const double cst = (double)(-p);
-                // n == R: solve with rows = queries; n < R: solve the transpose (rows = targets)
-                if (n == R) scratch[lf].cost[q * HMAX + lane] = cst;
-                else scratch[lf].cost[lane * HMAX + q] = cst;
+    const int f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int n = min(max(tgt_len[f], 0), R);
+    // phase 1: softmax statistics + gathered cost entries, cost = -softmax[q, tgt_j] (fp32) as float64
+    if (n > 0) {
+        // (a class id outside [0, C) is a caller error - the reference's out_prob[:, tgt_ids] raises IndexError,
+        // matcher.py:74; the host wrappers check it - here it is clamped so that the read stays inside the row)
+        const int64_t cls = lane < n ? min(max(tgt[(int64_t)f * R + lane], (int64_t)0), (int64_t)C - 1) : 0;
+        if constexpr (NV > 0) {
+            float val[HMAX][NV], picked[HMAX];
+#pragma unroll
+            for (int q = 0; q < HMAX; ++q) {
+                const T* row = logits + ((int64_t)f * R + min(q, R - 1)) * C;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) val[q][k] = lane + 64 * k < C ? to_f32(row[lane + 64 * k]) : -INFINITY;
+                picked[q] = to_f32(row[cls]);
+            }
+#pragma unroll
+            for (int q = 0; q < HMAX; ++q) {
+                if (q < R) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) mx = fmaxf(mx, val[q][k]);
+                    mx = wave_max(mx);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+                        if (lane + 64 * k < C) sum += expf(val[q][k] - mx);
+                    sum = wave_sum(sum);
+                    if (lane < n) {
+                        const double cst = (double)(-(expf(picked[q] - mx) / sum));
+                        // n == R: solve with rows = queries; n < R: solve the transpose (rows = targets)
+                        if (n == R) s.cost[q * HMAX + lane] = cst;
+                        else s.cost[lane * HMAX + q] = cst;
+                    }
+                }
+            }
+        } else {
+            for (int q = 0; q < R; ++q) {
+                const T* row = logits + ((int64_t)f * R + q) * C;
+                float mx = -INFINITY;
+                for (int c = lane; c < C; c += 64) mx = fmaxf(mx, to_f32(row[c]));
+                mx = wave_max(mx);
+                float sum = 0.f;
+                for (int c = lane; c < C; c += 64) sum += expf(to_f32(row[c]) - mx);
+                sum = wave_sum(sum);
+                if (lane < n) {
+                    const double cst = (double)(-(expf(to_f32(row[cls]) - mx) / sum));
+                    if (n == R) s.cost[q * HMAX + lane] = cst;
+                    else s.cost[lane * HMAX + q] = cst;
+                }
             }
         }
     }
     __syncthreads();
-    // phase 2: one lane per problem
-    if (lane < FRAMES_PER_WAVE) {
-        const int f = f0 + lane;
-        if (f < n_frames) {
-            const int n = min(max(tgt_len[f], 0), R);
-            LsapScratch& s = scratch[lane];
-            int64_t* oq = out_q + (int64_t)f * R;
-            int64_t* ot = out_t + (int64_t)f * R;
-            if (n > 0) {
-                if (n == R) lsap_wide(s, R, R); else lsap_wide(s, n, R);
-            }
-            emit_assignment(s, R, n, n != R, oq, ot);
-            if (out_grid) {
-                int64_t* g = out_grid + (int64_t)f * R;
-                for (int k = 0; k < R; ++k) g[k] = background;
-                for (int k = 0; k < n; ++k) g[oq[k]] = tgt[(int64_t)f * R + ot[k]];
-            }
+    // phase 2: the 8 x 8 solve is sequential (SciPy's scan order and tie rules): one lane
+    if (lane == 0) {
+        int64_t* oq = out_q + (int64_t)f * R;
+        int64_t* ot = out_t + (int64_t)f * R;
+        if (n > 0) {
+            if (n == R) lsap_wide(s, R, R); else lsap_wide(s, n, R);
+        }
+        emit_assignment(s, R, n, n != R, oq, ot);
+        if (out_grid) {
+            int64_t* g = out_grid + (int64_t)f * R;
+            for (int k = 0; k < R; ++k) g[k] = background;
+            for (int k = 0; k < n; ++k) g[oq[k]] = tgt[(int64_t)f * R + ot[k]];
         }
     }
 }
@@ -359,14 +384,14 @@ extern "C" int shg_hungarian_per_frame(const void* logits, int dtype, int n_fram
                                per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);
         return check_launch("hungarian_per_clip");
     }
-    dim3 grid((n_frames + FRAMES_PER_WAVE - 1) / FRAMES_PER_WAVE), block(64);
-    if (dtype == SHG_F32)
-        hipLaunchKernelGGL(hungarian_per_frame_kernel<float>, grid, block, 0, st, (const float*)logits, n_frames,
-                           per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);
-    else if (dtype == SHG_BF16)
-        hipLaunchKernelGGL(hungarian_per_frame_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)logits, n_frames,
-                           per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);
-    else return fail_arg("hungarian: bad dtype");
+    dim3 grid(n_frames), block(64);
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("hungarian: bad dtype");
+#define SHG_HPF(T, NV) hipLaunchKernelGGL((hungarian_per_frame_kernel<T, NV>), grid, block, 0, st, (const T*)logits, n_frames, \
+                                          per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid)
+#define SHG_HPF_T(T) do { if (n_classes <= 256) SHG_HPF(T, 4); else if (n_classes <= 512) SHG_HPF(T, 8); else SHG_HPF(T, 0); } while (0)
+    if (dtype == SHG_F32) SHG_HPF_T(float); else SHG_HPF_T(bf16_t);
+#undef SHG_HPF_T
+#undef SHG_HPF
     return check_launch("hungarian_per_frame");
 }
 

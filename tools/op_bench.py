@@ -66,3 +66,16 @@ if "wgrad" in which:
         gw = torch.zeros(n_out, n_in, device=dev)
         t = timeit(lambda: K.gemm(dy, x, gw, None, False, False, accumulate=True))
         print("wgrad rows %d  %d x %d: %.1f us (%.0f TFLOP/s)" % (rows, n_out, n_in, t, 2.0 * rows * n_out * n_in / t / 1e6), flush=True)
+if "colsum" in which:
+    for rows, cols in [(12576, 768), (12576, 2304), (12576, 3072), (4096, 768), (4096, 2048), (1536, 768), (640, 768)]:
+        x = torch.randn(rows, cols, device=dev).to(bf)
+        out = torch.zeros(cols, device=dev)
+        t = timeit(lambda: K.colsum(x, out, True))
+        print("colsum_accumulate %dx%d: %.1f us (%.2f TB/s)" % (rows, cols, t, rows * cols * 2 / t / 1e6), flush=True)
+if "hungarian" in which:
+    for frames, per, C in [(512, 8, 457), (512, 3, 158), (512, 8, 158), (4096, 8, 457)]:
+        logits = torch.randn(frames, per, C, device=dev).to(bf)
+        tgt = torch.randint(0, C - 1, (frames, per), device=dev)
+        lens = torch.randint(0, per + 1, (frames,), device=dev, dtype=torch.int32)
+        t = timeit(lambda: K.hungarian_per_frame(logits, tgt, lens))
+        print("hungarian_per_frame %d frames x %d queries x %d classes: %.1f us" % (frames, per, C, t), flush=True)
