@@ -19,6 +19,22 @@ __host__ inline int colsum_partials(int64_t rows) {
     return (int)n;
 }
 
+// V consecutive fp32 parameters (bias / gamma / beta slice of this lane's chunk) as 16-byte loads.  Per-element `p ? p[c] : 0`
+// inside the element loop compiled to one dependent 4-byte load + wait per element (8-16 serial L2 round trips per row: the
+// r-layer LayerNorm ran at 30 us where an add of the same traffic takes 10).  p == nullptr: zeros (wave-uniform branch).
+template <int V> __device__ __forceinline__ void load_param_vec(const float* __restrict__ p, int c0, float (&out)[V]) {
+    if (p) {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(p + c0 + 4 * q);
+            out[4 * q] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) out[j] = 0.f;
+    }
+}
+
 // FAST: bf16 storage (gelu_fast, common.h); the fp32 parity mode keeps libm's erff
 template <int ACT, bool FAST> __device__ __forceinline__ float act_fwd(float u) {
     if (ACT == SHG_ACT_GELU) return FAST ? gelu_fast(u) : gelu_erf(u);
@@ -34,7 +50,7 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_grad(float u)
 // ------------------------------------------------------------------------------------------------
 // forward: one wave per row
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT, int NCH>
+template <typename T, int ACT, int NCH, bool DROP>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                      const T* __restrict__ residual, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -48,8 +64,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = cols / V;
-    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
-    float zv[NCH][V];
+    const uint64_t seed = DROP ? dropout_seed(seed_state, stream_id) : 0;
+    float zv[NCH][V], gv[NCH][V], bev[NCH][V];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -60,11 +76,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             Vec16<T> xv = load16(x + off);
             Vec16<T> rv;
             if (residual) rv = load16(residual + off);
+            float bv[V];
+            load_param_vec<V>(bias, c0, bv);
+            load_param_vec<V>(gamma, c0, gv[i]);         // (used after the two reductions: in flight meanwhile)
+            load_param_vec<V>(beta, c0, bev[i]);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                float u = xv.get(j) + (bias ? bias[c0 + j] : 0.f);
+                float u = xv.get(j) + bv[j];
                 u = act_fwd<ACT, (sizeof(T) == 2)>(u);
-                if (drop_thr) u = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? u * drop_scale : 0.f;
+                if (DROP) u = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? u * drop_scale : 0.f;
                 if (residual) u += rv.get(j);
                 zv[i][j] = u;
                 sum += u;
@@ -104,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             const int c0 = ch * V;
             Vec16<T> yo;
 #pragma unroll
-            for (int j = 0; j < V; ++j) yo.set(j, (zv[i][j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j]);
+            for (int j = 0; j < V; ++j) yo.set(j, (zv[i][j] - mean) * rstd * gv[i][j] + bev[i][j]);
             store16(y + row * cols + c0, yo);
             if (y_pos) {                 // second output: y (as stored) + pos, rounded once (the decoder's `tgt + query_pos`)
                 const Vec16<T> pv = load16(pos + row * cols + c0);
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // backward: block = 4 waves, loops over its chunk of rows; per-lane column partials in registers,
 // reduced across the 4 waves through LDS, one partial row per block.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT, int NCH>
+template <typename T, int ACT, int NCH, bool DROP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                      const T* __restrict__ x, const float* __restrict__ bias,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -138,7 +158,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const int64_t rows_per_blk = (rows + nblk - 1) / nblk;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r_end = min(rows, r_begin + rows_per_blk);
-    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
+    const uint64_t seed = DROP ? dropout_seed(seed_state, stream_id) : 0;
 
     float ag[NCH][V], ab[NCH][V], abias[NCH][V];
 #pragma unroll
@@ -157,11 +177,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 const int c0 = ch * V;
                 const int64_t off = row * cols + c0;
                 Vec16<T> dv = load16(dy + off), zz = load16(z + off);
+                float gm[V];
+                load_param_vec<V>(gamma, c0, gm);        // (L1 / L2 hit; kept out of the registers that live across rows)
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     const float g = dv.get(j);
                     const float h = (zz.get(j) - mu) * rs;
-                    const float gy = g * gamma[c0 + j];
+                    const float gy = g * gm[j];
                     xh[i][j] = h; gyv[i][j] = gy;
                     s1 += gy; s2 += gy * h;
                     ag[i][j] += g * h; ab[i][j] += g;
@@ -177,14 +199,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 const int c0 = ch * V;
                 const int64_t off = row * cols + c0;
                 Vec16<T> dzv, dxv, xv;
-                if (ACT != SHG_ACT_NONE) xv = load16(x + off);
+                float bsv[V];
+                if (ACT != SHG_ACT_NONE) { xv = load16(x + off); load_param_vec<V>(bias, c0, bsv); }
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     const float dz = rs * (gyv[i][j] - s1 - xh[i][j] * s2);
                     dzv.set(j, dz);
                     float d = dz;
-                    if (drop_thr) d = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? d * drop_scale : 0.f;
-                    if (ACT != SHG_ACT_NONE) d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+                    if (DROP) d = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? d * drop_scale : 0.f;
+                    if (ACT != SHG_ACT_NONE) d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + bsv[j]);
                     dxv.set(j, d);
                     abias[i][j] += to_f32(from_f32<T>(d));
                 }
@@ -220,28 +243,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 // ------------------------------------------------------------------------------------------------
 // bias + activation + dropout
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT>
+template <typename T, int ACT, bool DROP>
 __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                            T* __restrict__ y, int64_t n_vec, int cols,
                                                            uint32_t drop_thr, float drop_scale,
                                                            const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
     constexpr int V = Vec16<T>::N;
-    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
+    const uint64_t seed = DROP ? dropout_seed(seed_state, stream_id) : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t off = i * V;
         const int c0 = (int)(off % cols);
         Vec16<T> xv = load16(x + off), yv;
+        float bv[V];
+        load_param_vec<V>(bias, c0, bv);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float u = act_fwd<ACT, (sizeof(T) == 2)>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
-            if (drop_thr) u = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? u * drop_scale : 0.f;
+            float u = act_fwd<ACT, (sizeof(T) == 2)>(xv.get(j) + bv[j]);
+            if (DROP) u = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? u * drop_scale : 0.f;
             yv.set(j, u);
         }
         store16(y + off, yv);
     }
 }
 
-template <typename T, int ACT, int NCH>
+template <typename T, int ACT, int NCH, bool DROP>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                            const T* __restrict__ dy, T* __restrict__ dx,
                                                            float* __restrict__ dbias_p, int64_t rows, int cols,
@@ -255,12 +280,14 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
     const int64_t rows_per_blk = (rows + nblk - 1) / nblk;
     const int64_t r_begin = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r_end = min(rows, r_begin + rows_per_blk);
-    const uint64_t seed = drop_thr ? dropout_seed(seed_state, stream_id) : 0;
-    float ab[NCH][V];
+    const uint64_t seed = DROP ? dropout_seed(seed_state, stream_id) : 0;
+    float ab[NCH][V], bsv[NCH][V];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
+    for (int i = 0; i < NCH; ++i) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) ab[i][j] = 0.f;
+        for (int j = 0; j < V; ++j) { ab[i][j] = 0.f; bsv[i][j] = 0.f; }
+        if (lane + i * 64 < nchunk) load_param_vec<V>(bias, (lane + i * 64) * V, bsv[i]);
+    }
     for (int64_t row = r_begin + wave; row < r_end; row += 4) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -272,8 +299,8 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     float d = gv.get(j);
-                    if (drop_thr) d = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? d * drop_scale : 0.f;
-                    d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + (bias ? bias[c0 + j] : 0.f));
+                    if (DROP) d = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? d * drop_scale : 0.f;
+                    d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + bsv[i][j]);
                     dv.set(j, d);
                     ab[i][j] += to_f32(from_f32<T>(d));
                 }
@@ -408,15 +435,18 @@ static int launch_ln_fwd(const void* x, const float* bias, const void* residual,
     const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const int nch = (cols / Vec16<T>::N + 63) / 64;
-#define LN_FWD2(ACT, NCH)                                                                                             \
-    hipLaunchKernelGGL((ln_fwd_kernel<T, ACT, NCH>), grid, block, 0, st, (const T*)x, bias, (const T*)residual, gamma, \
+    if (!aligned16(gamma) || !aligned16(beta) || (bias && !aligned16(bias))) return fail_arg("bias_act_drop_res_ln_fwd: bias / gamma / beta must be 16-byte aligned");
+#define LN_FWD3(ACT, NCH, DROP)                                                                                       \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, ACT, NCH, DROP>), grid, block, 0, st, (const T*)x, bias, (const T*)residual, gamma, \
                        beta, (T*)y, (T*)z_out, mean, rstd, (const T*)pos, (T*)y_pos, rows, cols, eps, thr, scale, seed_state, stream_id)
+#define LN_FWD2(ACT, NCH) do { if (thr) LN_FWD3(ACT, NCH, true); else LN_FWD3(ACT, NCH, false); } while (0)
 #define LN_FWD(ACT) do { if (nch <= 2) LN_FWD2(ACT, 2); else if (nch <= 4) LN_FWD2(ACT, 4); else LN_FWD2(ACT, 8); } while (0)
     if (act == SHG_ACT_NONE) LN_FWD(SHG_ACT_NONE);
     else if (act == SHG_ACT_GELU) LN_FWD(SHG_ACT_GELU);
     else LN_FWD(SHG_ACT_RELU);
 #undef LN_FWD
 #undef LN_FWD2
+#undef LN_FWD3
     return check_launch("bias_act_drop_res_ln_fwd");
 }
 
@@ -430,15 +460,18 @@ static int launch_ln_bwd(const void* dy, const void* z, const void* x, const flo
     dim3 grid(n_partials), block(256);
     const size_t lds = (size_t)12 * cols * sizeof(float);
     const int nch = (cols / Vec16<T>::N + 63) / 64;
-#define LN_BWD2(ACT, NCH)                                                                                            \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, ACT, NCH>), grid, block, lds, st, (const T*)dy, (const T*)z, (const T*)x, bias, \
+    if (!aligned16(gamma) || (bias && !aligned16(bias))) return fail_arg("bias_act_drop_res_ln_bwd: bias / gamma must be 16-byte aligned");
+#define LN_BWD3(ACT, NCH, DROP)                                                                                      \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, ACT, NCH, DROP>), grid, block, lds, st, (const T*)dy, (const T*)z, (const T*)x, bias, \
                        gamma, mean, rstd, (T*)dx, (T*)dres, dg, db, dbi, rows, cols, thr, scale, seed_state, stream_id)
+#define LN_BWD2(ACT, NCH) do { if (thr) LN_BWD3(ACT, NCH, true); else LN_BWD3(ACT, NCH, false); } while (0)
 #define LN_BWD(ACT) do { if (nch <= 2) LN_BWD2(ACT, 2); else if (nch <= 4) LN_BWD2(ACT, 4); else LN_BWD2(ACT, 8); } while (0)
     if (act == SHG_ACT_NONE) LN_BWD(SHG_ACT_NONE);
     else if (act == SHG_ACT_GELU) LN_BWD(SHG_ACT_GELU);
     else LN_BWD(SHG_ACT_RELU);
 #undef LN_BWD
 #undef LN_BWD2
+#undef LN_BWD3
     return check_launch("bias_act_drop_res_ln_bwd");
 }
 
@@ -687,10 +720,13 @@ extern "C" int shg_bias_act_fwd(const void* x, const float* bias, void* y, int d
     const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     dim3 grid((unsigned)std::min<int64_t>((n_vec + 255) / 256, 2048)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define BA_FWD(T, ACT) hipLaunchKernelGGL((bias_act_fwd_kernel<T, ACT>), grid, block, 0, st, (const T*)x, bias, (T*)y, n_vec, cols, thr, scale, seed_state, stream_id)
+    if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return fail_arg("bias_act_fwd: bias must be 16-byte aligned");
+#define BA_FWD1(T, ACT, DROP) hipLaunchKernelGGL((bias_act_fwd_kernel<T, ACT, DROP>), grid, block, 0, st, (const T*)x, bias, (T*)y, n_vec, cols, thr, scale, seed_state, stream_id)
+#define BA_FWD(T, ACT) do { if (thr) BA_FWD1(T, ACT, true); else BA_FWD1(T, ACT, false); } while (0)
     if (dtype == SHG_F32) { if (act == 0) BA_FWD(float, 0); else if (act == 1) BA_FWD(float, 1); else BA_FWD(float, 2); }
     else { if (act == 0) BA_FWD(bf16_t, 0); else if (act == 1) BA_FWD(bf16_t, 1); else BA_FWD(bf16_t, 2); }
 #undef BA_FWD
+#undef BA_FWD1
     return check_launch("bias_act_fwd");
 }
 
@@ -707,11 +743,14 @@ extern "C" int shg_bias_act_bwd(const void* x, const float* bias, const void* dy
     const size_t lds = (size_t)4 * cols * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const int nch = (cols / (dtype == SHG_BF16 ? 8 : 4) + 63) / 64;
-#define BA_BWD2(T, ACT, NCH) hipLaunchKernelGGL((bias_act_bwd_kernel<T, ACT, NCH>), grid, block, lds, st, (const T*)x, bias, (const T*)dy, (T*)dx, dbias_partial, rows, cols, thr, scale, seed_state, stream_id)
+    if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return fail_arg("bias_act_bwd: bias must be 16-byte aligned");
+#define BA_BWD3(T, ACT, NCH, DROP) hipLaunchKernelGGL((bias_act_bwd_kernel<T, ACT, NCH, DROP>), grid, block, lds, st, (const T*)x, bias, (const T*)dy, (T*)dx, dbias_partial, rows, cols, thr, scale, seed_state, stream_id)
+#define BA_BWD2(T, ACT, NCH) do { if (thr) BA_BWD3(T, ACT, NCH, true); else BA_BWD3(T, ACT, NCH, false); } while (0)
 #define BA_BWD(T, ACT) do { if (nch <= 2) BA_BWD2(T, ACT, 2); else if (nch <= 4) BA_BWD2(T, ACT, 4); else if (nch <= 8) BA_BWD2(T, ACT, 8); else BA_BWD2(T, ACT, 16); } while (0)
     if (dtype == SHG_F32) { if (act == 0) BA_BWD(float, 0); else if (act == 1) BA_BWD(float, 1); else BA_BWD(float, 2); }
     else { if (act == 0) BA_BWD(bf16_t, 0); else if (act == 1) BA_BWD(bf16_t, 1); else BA_BWD(bf16_t, 2); }
 #undef BA_BWD
 #undef BA_BWD2
+#undef BA_BWD3
     return check_launch("bias_act_bwd");
 }
