@@ -341,7 +341,8 @@ typedef struct shg_run {
     const uint64_t* seed_state;
     int32_t defer_wgrad;      /* != 0 (needs wgrad_stream): weight / bias gradients are queued on `exec` instead of launched; the
                                  caller keeps their operands alive and calls shg_exec_flush_wgrads (grouped launches) */
-    int32_t pad_;
+    int32_t kv_ahead;         /* != 0 (needs wgrad_stream): shg_decoder_fwd issues the key / value projections of `memory` for ALL
+                                 layers on wgrad_stream (idle during a forward pass) behind one event, and the chain waits per layer */
 } shg_run_t;
 
 typedef struct shg_linear {

@@ -105,7 +105,7 @@ class DecoderLayerT(ctypes.Structure):
 
 class RunT(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int32), ("training", ctypes.c_int32), ("stream", c_void_p), ("wgrad_stream", c_void_p),
-                ("exec", c_void_p), ("seed_state", c_void_p), ("defer_wgrad", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("exec", c_void_p), ("seed_state", c_void_p), ("defer_wgrad", ctypes.c_int32), ("kv_ahead", ctypes.c_int32)]
 
 
 class WgradProblemT(ctypes.Structure):

@@ -1170,7 +1170,9 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         for (int part = 0; part < d.parts; ++part) {
             const int sl = 2 * d.tile + part;
             if (tid == 0) {
-                while (__hip_atomic_load(sk.flags + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+                // (relaxed polls: an ACQUIRE load at agent scope invalidates the XCD's L2 on EVERY poll - under the tails that are
+                //  still streaming their operand panels through it; the one acquire fence below orders the reads of the slot)
+                while (__hip_atomic_load(sk.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
                 __hip_atomic_store(sk.flags + sl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();

@@ -72,6 +72,7 @@ class Engine:
         # weight gradients of the executor calls are queued and go out as grouped launches once ~a chip's worth of 256 x 256
         # tiles is pending (SHG_WGRAD_DEFER=0: every weight gradient is its own launch, issued at once)
         self.defer_wgrads = os.environ.get("SHG_WGRAD_DEFER", "1") != "0"
+        self.kv_ahead = int(os.environ.get("SHG_KV_AHEAD", "0"))
         self.wgrad_flush_tiles = int(os.environ.get("SHG_WGRAD_FLUSH_TILES", "224"))
         self.pending_keep, self.pending_params = [], []
         self._exec = None                 # shg_exec_t* of the sub-layer executor (event ring for the weight-gradient stream)
@@ -127,6 +128,12 @@ class Engine:
         side = self.wgrad_stream()
         R.wgrad_stream = side.cuda_stream if side is not None else None
         R.defer_wgrad = 1 if (side is not None and self.defer_wgrads) else 0
+        # decoder key / value projections of the encoder memory ahead of the chain, on the weight-gradient stream (idle in a
+        # forward pass).  SHG_KV_AHEAD: 0 off (default), 1 only for a decoder issued on the main stream, 2 for every decoder.
+        # Measured: -0.5 ms per step when the branches run inline (SHG_BRANCH_MASK=0: 27.76 -> 27.25 ms), nothing with the two
+        # branch streams on (23.1-23.3 either way): beside three busy streams the step is bound by the chip's throughput, not
+        # by the length of the decoder chain
+        R.kv_ahead = 1 if (side is not None and (self.kv_ahead == 2 or (self.kv_ahead == 1 and not self._on_branch_stream()))) else 0
         if side is not None:
             self.unjoined.add(side.cuda_stream)
         R.seed_state = self.seed_state.data_ptr()
@@ -260,6 +267,10 @@ class Engine:
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         return self._wgrad_stream
+
+    def _on_branch_stream(self):
+        cur = torch.cuda.current_stream().cuda_stream
+        return any(s.cuda_stream == cur for s in self._aux_streams.values())
 
     def aux_stream(self, i):
         """Side stream for an independent branch of the model (None: run it inline)."""
