@@ -126,3 +126,32 @@ def test_decoder_layer_fused_sublayers(train):
     mem = torch.randn(2, 56, 128, generator=gen).to(DEV)
     tmask = rel_target_mask_device(8, 4, DEV).float().contiguous()          # block-causal [32, 32]
     _check(E, lambda t, qp, m: layer.forward_bf(t, m, qp, tmask), [tgt, pos, mem])
+
+
+def test_decoder_kv_ahead_gives_the_same_bits():
+    """shg_run_t.kv_ahead moves the key / value projections of the encoder memory to the weight-gradient stream, ahead of the
+    chain (one event per layer): same kernels, same operands - outputs and gradients must not change by a bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from shg_vqa_amd.entry import rel_target_mask_device
+    from shg_vqa_amd.transformer import TransformerDecoder, TransformerDecoderLayer
+    res = {}
+    for mode in (0, 2):
+        torch.manual_seed(7)
+        dec = TransformerDecoder(TransformerDecoderLayer(128, 2, dim_feedforward=256, dropout=0.15), 3)
+        E = _adopt(dec, True)
+        E.kv_ahead = mode
+        gen = torch.Generator().manual_seed(5)
+        pos = torch.randn(2, 32, 128, generator=gen).to(DEV).requires_grad_(True)
+        mem = torch.randn(2, 56, 128, generator=gen).to(DEV).requires_grad_(True)
+        tmask = rel_target_mask_device(8, 4, DEV).float().contiguous()
+        E.begin_step()
+        y = dec.forward_bf(None, mem, pos, tmask)
+        E.zero_grad()
+        y.float().square().sum().backward()
+        E.join_side_streams()
+        torch.cuda.synchronize()
+        res[mode] = (y.detach().clone(), mem.grad.clone(), pos.grad.clone(), E.grad_arena.clone())
+    for a, b in zip(res[0], res[2]):
+        assert torch.equal(a, b)
+    assert res[0][3].abs().max() > 0
