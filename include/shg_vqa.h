@@ -256,6 +256,11 @@ int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y
                         void* streamk_workspace, void* stream);
 int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                           int Cin, int Cout, int accumulate, const void* workspace, void* stream);
+/* the same for the output channels [c0, c0 + cn) only (multiples of 8): rows c0.. of dw, columns c0.. of dy.  A data-parallel
+ * step issues conv1's weight gradient (283 MB of fp32 gradients, the last kernel of backward) as two such launches, so that the
+ * all-reduce of the first two thirds runs under the last third instead of behind everything. */
+int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin,
+                                int Cout, int c0, int cn, int accumulate, const void* workspace, void* stream);
 int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
                           int Cin, int Cout, const void* workspace, void* stream);
 /* NCDHW fp32 features -> channels-last, spatially zero-padded (dtype) : [B,C,T,H,W] -> [B,T,H+2,W+2,C] */

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "shg_streamk_workspace_bytes": ([], c_int64),
     "shg_streamk_workspace_init": ([P, P], c_int),
     "shg_conv3d_k533_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, P, P], c_int),
+    "shg_conv3d_k533_wgrad_slice": ([P, P, P, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
     "shg_conv3d_k533_dgrad": ([P, P, P, I, I, I, I, I, I, I, P, P], c_int),
     "shg_ncdhw_to_padded_cl": ([P, P, I, I, I, I, I, I, P], c_int),
     "shg_sumsq": ([P, L, P, I, P, P], c_int),

@@ -1709,33 +1709,40 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);
 }
 
-extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
-                                     int Cin, int Cout, int accumulate, const void* workspace, void* stream) {
+extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
+                                           int Cin, int Cout, int c0, int cn, int accumulate, const void* workspace, void* stream) {
     if (!x || !dy || !dw) return fail_arg("conv3d_wgrad: null pointer");
     if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
+    if (c0 < 0 || cn < 1 || c0 + cn > Cout || c0 % 8 || cn % 8) return fail_arg("conv3d_wgrad: bad output-channel slice (multiples of 8 inside [0, Cout))");
     if (!al16(x) || !al16(dy) || !al16(dw)) return fail_arg("conv3d_wgrad: pointers must be 16-byte aligned");
-    // dW[co][(tap, ci)] = sum_m dY[m][co] * Xgather[m][(tap, ci)] : GEMM with M' = Cout, N' = 45*Cin, K' = M
+    // dW[co][(tap, ci)] = sum_m dY[m][co] * Xgather[m][(tap, ci)] : GEMM with M' = Cout, N' = 45*Cin, K' = M; an output-channel
+    // slice [c0, c0 + cn) is the rows c0.. of that GEMM: columns c0.. of dY (row stride Cout), rows c0.. of dW (contiguous)
     const int64_t Mo = (int64_t)B * (T - 4) * H * W, Ncols = (int64_t)45 * Cin;
     const int32_t* pos_in = (const int32_t*)workspace;
     ConvGeom g = conv_geom(Cin, H + 2, W + 2);
     hipStream_t st = (hipStream_t)stream;
-    Epilogue<float> ep{dw, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1, nullptr, 0};
+    Epilogue<float> ep{dw + (int64_t)c0 * Ncols, Ncols, nullptr, nullptr, SHG_ACT_NONE, accumulate, 1, nullptr, 0};
     if (dtype == SHG_F32) {
-        PlainSrc<float, false> sa{(const float*)dy, Cout, 0, Cout, Mo};
+        PlainSrc<float, false> sa{(const float*)dy + c0, Cout, 0, cn, Mo};
         ConvColSrc<float, 256> sb{(const float*)x, pos_in, 0, Ncols, Mo, g};
-        return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
+        return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, cn, Ncols, Mo, st, "conv3d_k533_wgrad", false);
     }
-    PlainSrc<bf16_t, false> sa{(const bf16_t*)dy, Cout, 0, Cout, Mo};
-    if (use_gemm8(Cout, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
+    PlainSrc<bf16_t, false> sa{(const bf16_t*)dy + c0, Cout, 0, cn, Mo};
+    if (use_gemm8(cn, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
-        return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad");
+        return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, Ncols, Mo, st, "conv3d_k533_wgrad");
     }
-    if (use_large(1, Cout, Ncols, Mo)) {
+    if (use_large(1, cn, Ncols, Mo)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
-        return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
+        return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, cn, Ncols, Mo, st, "conv3d_k533_wgrad", false);
     }
     ConvColSrc<bf16_t, 256> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
-    return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, Cout, Ncols, Mo, st, "conv3d_k533_wgrad", false);
+    return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, cn, Ncols, Mo, st, "conv3d_k533_wgrad", false);
+}
+
+extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
+                                     int Cin, int Cout, int accumulate, const void* workspace, void* stream) {
+    return shg_conv3d_k533_wgrad_slice(x, dy, dw, dtype, B, T, H, W, Cin, Cout, 0, Cout, accumulate, workspace, stream);
 }
 
 extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,

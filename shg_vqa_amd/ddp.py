@@ -7,7 +7,9 @@ Design for MI355X / xGMI:
     xGMI is point-to-point, so per-collective latency matters more than on a switch).  Bucket bounds
     follow PARAMETER bounds: a large tensor (conv1's 283 MB weight gradient) is cut into buckets of its
     own, so its exchange starts the moment its weight-gradient kernel has been enqueued and does not
-    wait for neighbours in the arena that are written much later (the embeddings);
+    wait for neighbours in the arena that are written much later (the embeddings); with a reducer attached the conv stack's
+    backward issues conv2's weight gradient first and conv1's as two launches over output channels (2/3 + 1/3: the same number
+    of tile rounds as one launch), so that only the last third of the largest gradient is exchanged behind backward;
   * every backward op reports the slice it has just finished (Engine.grad_written); a bucket whose
     expected number of writes has arrived is all-reduced immediately on a side stream, overlapping
     the remaining backward GEMMs.  The expected counts are learned during the first step (shared

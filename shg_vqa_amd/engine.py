@@ -331,10 +331,11 @@ class Engine:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def grad_written(self, p):
+    def grad_written(self, p, first=0, count=None):
+        """The gradient of parameter p - or its elements [first, first + count) - has just been enqueued."""
         self.grad_dirty = True
         if self.grad_ready_hook is not None:
-            self.grad_ready_hook(p._shg_off, p._shg_numel)
+            self.grad_ready_hook(p._shg_off + first, p._shg_numel - first if count is None else count)
 
 
 def _storage_layout(p):

@@ -432,8 +432,9 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, wan
     return (out, pre) if want_pre else out
 
 
-def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False):
-    """dw [Cout,5,3,3,Cin] fp32 (+)= sum over positions of dy [B,T-4,H,W,Cout] x gathered x_cl."""
+def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False, c0=0, cn=None):
+    """dw [Cout,5,3,3,Cin] fp32 (+)= sum over positions of dy [B,T-4,H,W,Cout] x gathered x_cl; c0 / cn: only the output
+    channels [c0, c0 + cn) (rows of dw)."""
     _dev(x_cl, dy, dw)
     B, T, Hp, Wp, cin = x_cl.shape
     H, W = Hp - 2, Wp - 2
@@ -442,8 +443,12 @@ def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False):
           "dy must be contiguous [B,T-4,H,W,Cout] of x's dtype")
     _need(tuple(dw.shape) == (cout, 5, 3, 3, cin) and dw.dtype == torch.float32 and dw.is_contiguous(), "dw fp32 [Cout,5,3,3,Cin]")
     ws = conv_workspace(B, T, H, W, x_cl.device)
-    _lib.call("shg_conv3d_k533_wgrad", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
-              1 if accumulate else 0, ws.data_ptr(), _stream())
+    if c0 == 0 and (cn is None or cn == cout):
+        _lib.call("shg_conv3d_k533_wgrad", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
+                  1 if accumulate else 0, ws.data_ptr(), _stream())
+    else:
+        _lib.call("shg_conv3d_k533_wgrad_slice", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
+                  int(c0), int(cn), 1 if accumulate else 0, ws.data_ptr(), _stream())
     return dw
 
 

@@ -511,7 +511,20 @@ class _VisualConvTokens(torch.autograd.Function):
         inline = os.environ.get("SHG_CONV_WGRAD_INLINE", "1") != "0"
         d1, part1 = K.bias_act_bwd(pre1, None, d_y1, ACT_GELU, want_dbias=True)
         _acc_vec(part1, b1)
-        if inline:
+        if inline and E.grad_ready_hook is not None and os.environ.get("SHG_CONV_WGRAD_SPLIT", "1") != "0":
+            # data parallel: conv1's gradient is a quarter of the step's all-reduce bytes and the LAST kernel of backward.
+            # conv2's weight gradient goes first (its exchange runs under conv1's), and conv1's leaves as two launches over
+            # output channels - 2/3 (720 tiles of 256 x 256 = 3 rounds on 256 CUs) and 1/3 (360 tiles = 2 rounds: the same
+            # five rounds as one launch of 1 080) - so that the exchange of the first part runs under the second.
+            K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+            E.grad_written(w2)
+            cout, per = w1._shg_grad.shape[0], w1._shg_grad[0].numel()
+            cut = (cout // 256) * 2 // 3 * 256
+            parts = [(0, cut), (cut, cout - cut)] if 0 < cut < cout else [(0, cout)]
+            for c0, cn in parts:
+                K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True, c0=c0, cn=cn)
+                E.grad_written(w1, c0 * per, cn * per)
+        elif inline:
             K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
             E.grad_written(w1)
             K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)

@@ -901,6 +901,12 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     assert torch.equal(dw.view(Cout, -1), ref), (dw.view(Cout, -1) - ref).abs().max()
     K.conv3d_k533_wgrad(xi.bfloat16(), dyi.bfloat16(), dw, accumulate=True)
     assert torch.equal(dw.view(Cout, -1), 2 * ref)
+    # output-channel slices (the data-parallel step issues conv1's gradient as 2/3 + 1/3, ops._VisualConvTokens.backward)
+    dw.zero_()
+    K.conv3d_k533_wgrad(xi.bfloat16(), dyi.bfloat16(), dw, c0=512, cn=256)
+    assert torch.equal(dw.view(Cout, -1)[512:], ref[512:]) and not dw[:512].any()
+    K.conv3d_k533_wgrad(xi.bfloat16(), dyi.bfloat16(), dw, c0=0, cn=512)
+    assert torch.equal(dw.view(Cout, -1), ref)
     del ref, xi, dyi
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
     xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
