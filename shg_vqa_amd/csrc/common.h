@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/shg_vqa.h"
 
 typedef __bf16 bf16_t;
@@ -21,6 +23,17 @@ namespace shg {
 void set_error(const char* msg);
 int fail_arg(const char* msg);           // records msg, returns SHG_ERR_INVALID
 int check_launch(const char* what);      // hipGetLastError -> 0 or positive hipError_t
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one bit per device in a per-instantiation mask
+// (true: the attribute has already been set for the current device)
+inline bool lds_limit_raised(std::atomic<uint64_t>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    const uint64_t bit = (uint64_t)1 << dev;
+    if (mask.load(std::memory_order_relaxed) & bit) return true;
+    mask.fetch_or(bit, std::memory_order_relaxed);
+    return false;
+}
 
 // ------------------------------------------------------------------ scalar conversion
 template <typename T> __device__ __forceinline__ float to_f32(T v);

@@ -840,11 +840,9 @@ static int launch4(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
     const int64_t gm = (M + 127) / 128, gn = (N + 127) / 128;
     const size_t lds = 4 * 4 * Tile64<bf16_t>::BYTES;
     auto kern = gemm4_kernel<TC, SrcA, SrcB>;
-    static bool raised = false;
-    if (!raised) {
+    static std::atomic<uint64_t> raised{0};          // per instantiation, one bit per device
+    if (!lds_limit_raised(raised))
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        raised = true;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn)), dim3(512), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn));
     return check_launch(what);
 }
@@ -1288,15 +1286,7 @@ static StreamK streamk_view(void* ws) {
     return sk;
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (instantiation, device)
-static bool lds_raised(std::atomic<uint64_t>& mask) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
-    const uint64_t bit = (uint64_t)1 << dev;
-    if (mask.load(std::memory_order_relaxed) & bit) return true;
-    mask.fetch_or(bit, std::memory_order_relaxed);
-    return false;
-}
+static bool lds_raised(std::atomic<uint64_t>& mask) { return lds_limit_raised(mask); }   // (common.h)
 
 static std::atomic<int64_t> g_streamk_launches{0};
 static int streamk_sigma() {

@@ -370,11 +370,10 @@ extern "C" int shg_hungarian_per_frame(const void* logits, int dtype, int n_fram
         const size_t lds = (size_t)per_frame * per_frame * 4 + 3 * (size_t)per_frame * 8 + 5 * (size_t)per_frame * 4 +
                            2 * (size_t)per_frame + 64;
         if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("hungarian: bad dtype");
-        static bool raised = false;
-        if (!raised) {
+        static std::atomic<uint64_t> raised{0};      // one bit per device
+        if (!lds_limit_raised(raised)) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(hungarian_wave_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             hipFuncSetAttribute(reinterpret_cast<const void*>(hungarian_wave_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            raised = true;
         }
         if (dtype == SHG_F32)
             hipLaunchKernelGGL(hungarian_wave_kernel<float>, dim3(n_frames), dim3(64), lds, st, (const float*)logits, n_frames,
