@@ -74,6 +74,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the same sum on the DPP network instead of six ds_bpermute round trips through the LDS crossbar (~100 cycles each, dependent):
+// quad swaps, row_half_mirror and row_mirror leave every lane with the sum of its row of 16; row_bcast:15 / :31 (gfx9 / CDNA
+// only) carry the row sums into the last row; lane 63 is broadcast.  The association order differs from wave_sum's butterfly:
+// kernels whose bits are pinned by a golden (the matcher's softmax) keep wave_sum.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_take(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_take<0xB1, 0xF>(v);         // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v);         // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v);        // row_half_mirror
+    v += dpp_take<0x140, 0xF>(v);        // row_mirror
+    v += dpp_take<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -107,14 +107,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
                 for (int j = 0; j < V; ++j) { zv[i][j] = to_f32(from_f32<T>(zv[i][j])); sum += zv[i][j]; }
     }
-    const float mean = wave_sum(sum) / (float)cols;
+    const float mean = wave_sum_dpp(sum) / (float)cols;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
         if (lane + i * 64 < nchunk)
 #pragma unroll
             for (int j = 0; j < V; ++j) { const float d = zv[i][j] - mean; sq += d * d; }
-    const float var = wave_sum(sq) / (float)cols;
+    const float var = wave_sum_dpp(sq) / (float)cols;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                 }
             }
         }
-        s1 = wave_sum(s1) / (float)cols;
-        s2 = wave_sum(s2) / (float)cols;
+        s1 = wave_sum_dpp(s1) / (float)cols;
+        s2 = wave_sum_dpp(s2) / (float)cols;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + i * 64;
