@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
                         s[n][kt][r] = t;
                         mx = fmaxf(mx, t);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = xrow_max(mx);
                 const float m_new = fmaxf(m_run[n], mx);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 alpha[n] = fast_exp2(m_run[n] - m_use);
@@ -178,8 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
                             p = dropout_keep_run(seed, (drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? p * P.drop_scale : 0.f;
                         s[n][kt][r] = p;
                     }
-                rs += __shfl_xor(rs, 16, 64);
-                rs += __shfl_xor(rs, 32, 64);
+                rs = xrow_sum(rs);
                 l_run[n] = l_run[n] * alpha[n] + rs;
                 m_run[n] = m_new;
             }
@@ -256,8 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
         float d = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) d += to_f32(of0.v[j]) * to_f32(df[n][0].v[j]) + to_f32(of1.v[j]) * to_f32(df[n][1].v[j]);
-        d += __shfl_xor(d, 16, 64);
-        d += __shfl_xor(d, 32, 64);
+        d = xrow_sum(d);
         const int64_t stat = ((int64_t)b * P.H + h) * P.Sq + qrow[n];
         if (g == 0 && qidx[n] < P.Sq) delta[stat] = d;
         dl[n] = d;

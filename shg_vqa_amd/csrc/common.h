@@ -90,6 +90,22 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += dpp_take<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// reductions over the four rows of 16 lanes (lanes l, l ^ 16, l ^ 32, l ^ 48 - the owners of one attention-score row), result
+// in all four: v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd rows / the upper half with the other operand's
+// even rows / lower half, so op(vdst, src) is the xor-16 / xor-32 step of a butterfly - a VALU instruction each instead of
+// a ds_bpermute round trip; the association order is the butterfly's, so the bits are those of the __shfl_xor form.
+__device__ __forceinline__ float xrow_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float xrow_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
