@@ -457,3 +457,26 @@ def test_whole_step_hipgraph_replay_matches_eager_steps():
         losses.append(out)
     for a, b in zip(*losses):
         assert abs(a - b) <= 2e-3 * abs(a), losses
+
+
+def test_command_line_trains_saves_and_tests(tmp_path):
+    """`python -m shg_vqa_amd.agqa_hgqa` with the reference's flags (agqaHGQA.py:877-1075, the headline configuration of
+    BASELINE.json on the synthetic split): one epoch of training with validation and checkpoints, then --test valid,test from
+    the saved weights with the per-category report."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--noCaps", "--crossAttnType", "cross", "--taskHGQA", "--fromScratch", "--LossHGPerFrame", "--batchSize", "8",
+             "--output", str(tmp_path)]
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "shg_vqa_amd.agqa_hgqa", "--epochs", "1", "--valid", "valid"] + flags,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Epoch 0: Valid" in r.stdout and "Rel class error" in r.stdout, r.stdout[-2000:]
+    for f in ("BEST.pth", "LAST.pth"):
+        assert (tmp_path / f).exists()
+    r = subprocess.run([sys.executable, "-m", "shg_vqa_amd.agqa_hgqa", "--test", "valid,test", "--load", str(tmp_path / "BEST")] + flags,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Valid HQ results:" in r.stdout and "Test:" in r.stdout and "overall:" in r.stdout, r.stdout[-2000:]
+    assert (tmp_path / "test_predictions.json").exists()
