@@ -179,6 +179,7 @@ template <typename T, int NTHR> struct ConvColSrc {
     int64_t r0, R, K;         // r0: first (tap, channel) column of this block; R = 45 * Cin; K = M
     ConvGeom g;
     int32_t posreg[Stage<T>::NCH];      // gather positions of the NEXT K-step, fetched one step ahead
+    int64_t cbase = 0;                  // a launch over the column blocks [cbase, cbase + N) of the problem: r0 counts from cbase
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void prefetch(int tid, int64_t k0) {
 #pragma unroll
@@ -190,7 +191,7 @@ template <typename T, int NTHR> struct ConvColSrc {
     }
     __device__ __forceinline__ const T* addr(int, int t, int row, int ch, int64_t k0, bool& ok) const {
         const int64_t m = k0 + row;
-        const int64_t c = r0 + 64 * t + ch * Tile64<T>::EPC;
+        const int64_t c = cbase + r0 + 64 * t + ch * Tile64<T>::EPC;
         ok = m < K && c < R;
         const int64_t mm = ok ? m : 0;
         const int tap = (int)(c / g.Cin);
@@ -207,14 +208,14 @@ template <typename T, int NTHR> struct ConvColSrc {
     }
     __device__ __forceinline__ uint32_t lane_off(int, int, int) const { return 0; }
     __device__ __forceinline__ const char* k_base(int i, int64_t) const {
-        uint32_t cb = (uint32_t)(r0 + 64 * i);
+        uint32_t cb = (uint32_t)(cbase + r0 + 64 * i);
         if (cb >= (uint32_t)R) cb = 0;
         const uint32_t tap = div_cin(g, cb), c0 = cb - tap * (uint32_t)g.Cin;
         return reinterpret_cast<const char*>(x + tap_offset(g, (int)tap) + c0);
     }
     __device__ __forceinline__ const T* gaddr(int i, int t, int, int ch, int64_t) const {
         // a 64-wide column block never straddles a tap (Cin % 64 == 0): tap and channel base are uniform
-        uint32_t cb = (uint32_t)(r0 + 64 * t);
+        uint32_t cb = (uint32_t)(cbase + r0 + 64 * t);
         if (cb >= (uint32_t)R) cb = 0;
         const uint32_t tap = div_cin(g, cb), c0 = cb - tap * (uint32_t)g.Cin;
         return x + (int64_t)posreg[i] * g.Cin + tap_offset(g, (int)tap) + c0 + ch * Tile64<T>::EPC;
@@ -1720,6 +1721,23 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
     PlainSrc<bf16_t, false> sa{(const bf16_t*)dy + c0, Cout, 0, cn, Mo};
     if (use_gemm8(cn, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
+        // Tile-count quantisation: conv1's 3 x 360 = 1 080 tiles are 4.22 rounds of 256 CUs - the fifth round runs 56
+        // workgroups for the full K = 18 816 while 200 CUs idle (0.36 ms of a 2.3 ms launch, the last kernel of backward).
+        // The column blocks of the whole rounds go out as one launch; the remaining blocks as a second launch with the
+        // contraction split over gridDim.y (fp32 atomic adds into the running sum - which is why this needs `accumulate`),
+        // so that the remainder takes a fraction of a round.  SHG_CONV_WGRAD_REMAINDER=0 switches it off.
+        static const int rem_on = []() { const char* e = getenv("SHG_CONV_WGRAD_REMAINDER"); return e ? atoi(e) : 1; }();
+        const int64_t tiles_m = (cn + 255) / 256, gn = Ncols / 256, total = tiles_m * gn, rounds = total / 256, rem = total % 256;
+        if (rem_on && accumulate && Ncols % 256 == 0 && rounds >= 1 && rem > 0 && Mo / BK >= 16) {
+            const int64_t gn_a = rounds * 256 / tiles_m, gn_b = gn - gn_a, tiles_b = tiles_m * gn_b;
+            const int split = (int)std::min<int64_t>(8, std::min<int64_t>(256 / std::max<int64_t>(tiles_b, 1), Mo / BK / 8));
+            if (gn_a >= 1 && gn_b >= 1 && split >= 2) {
+                if (int e = launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_a * 256, Mo, st, "conv3d_k533_wgrad")) return e;
+                sb.cbase = gn_a * 256;
+                ep.c += gn_a * 256;
+                return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_b * 256, Mo, st, "conv3d_k533_wgrad", split);
+            }
+        }
         return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, Ncols, Mo, st, "conv3d_k533_wgrad");
     }
     if (use_large(1, cn, Ncols, Mo)) {
