@@ -1730,8 +1730,15 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
         const int64_t tiles_m = (cn + 255) / 256, gn = Ncols / 256, total = tiles_m * gn, rounds = total / 256, rem = total % 256;
         if (rem_on && accumulate && Ncols % 256 == 0 && rounds >= 1 && rem > 0 && Mo / BK >= 16) {
             const int64_t gn_a = rounds * 256 / tiles_m, gn_b = gn - gn_a, tiles_b = tiles_m * gn_b;
-            const int split = (int)std::min<int64_t>(8, std::min<int64_t>(256 / std::max<int64_t>(tiles_b, 1), Mo / BK / 8));
-            if (gn_a >= 1 && gn_b >= 1 && split >= 2) {
+            // split of the remainder launch: the one with the shortest modelled time (rounds of 256 workgroups, each
+            // 19 us + 1.52 us per K-tile - the kernel's measured K scan), if that beats one plain round by 30 %
+            // (conv2's 149 remainder tiles at a split of three: modelled 236 against 317 us, measured 594 against 576 us for the launch)
+            const double nk = (double)(Mo / BK);
+            auto model = [&](int sp) { return (double)((tiles_b * sp + 255) / 256) * (19.0 + nk / sp * 1.52); };
+            int split = 1;
+            for (int sp = 2; sp <= 8 && nk / sp >= 8.0; ++sp)
+                if (model(sp) < model(split)) split = sp;
+            if (gn_a >= 1 && gn_b >= 1 && split >= 2 && model(split) < 0.7 * model(1)) {
                 if (int e = launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_a * 256, Mo, st, "conv3d_k533_wgrad")) return e;
                 sb.cbase = gn_a * 256;
                 ep.c += gn_a * 256;
