@@ -288,3 +288,50 @@ def test_synthetic_split_carries_evaluator_annotations_and_the_cli_parses_the_re
     assert int(it["target"].argmax()) == t.dataset.answer_index(5)
     a = parse_args(["--taskHGQA", "--noCaps", "--LossHGPerFrame", "--test", "valid,test", "--indirectRef", "--multiGPU", "--load", "x"])
     assert a.indirect_ref and a.multiGPU and a.test == "valid,test" and not a.novel_comp
+
+
+class _TinyBackbone(torch.nn.Module):
+    """Stand-in for VideoBackbone (video_encoder.py): frozen, `encode` maps (B, 3, T, H, W) to (B, C, T, H', W')."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.conv = torch.nn.Conv3d(3, 16, (1, 2, 2), stride=(1, 2, 2))
+
+    def encode(self, x):
+        return self.conv(x)
+
+
+def tiny_backbone():
+    return _TinyBackbone()
+
+
+def test_precompute_features_fills_the_cache_the_loader_reads(tmp_path):
+    """precompute_features.py: the frozen backbone once per clip (agqa_model.py:197 runs it in every step) -> the bf16
+    channels-last cache of feature_cache.py; also the conversion of already extracted features, and the command line."""
+    from shg_vqa_amd import precompute_features as P
+    from shg_vqa_amd.feature_cache import FeatureCache
+    gen = torch.Generator().manual_seed(4)
+    clips = tmp_path / "clips"
+    clips.mkdir()
+    frames = {}
+    for i in range(5):
+        frames["v%02d" % i] = torch.randn(3, 4, 8, 8, generator=gen)
+        torch.save(frames["v%02d" % i], clips / ("v%02d.pt" % i))
+    net = _TinyBackbone()
+    assert P.precompute(net, str(clips), str(tmp_path / "cache"), batch_size=2) == 5
+    cache = FeatureCache(str(tmp_path / "cache"))
+    assert cache.ids == sorted(frames) and cache.shape == (4, 4, 4, 16)
+    with torch.no_grad():
+        for k, vid in enumerate(cache.ids):
+            want = net.encode(frames[vid][None])[0].permute(1, 2, 3, 0).to(torch.bfloat16)
+            assert torch.equal(cache[k], want), vid
+    feats = tmp_path / "feats"
+    feats.mkdir()
+    with torch.no_grad():
+        np.save(feats / "a.npy", net.encode(frames["v00"][None])[0].numpy())
+    assert P.main(["--features", str(feats), "--out", str(tmp_path / "c2")]) == 0
+    assert torch.equal(FeatureCache(str(tmp_path / "c2"))[0], cache[0])
+    assert P.main(["--backbone", "tests.test_host_cpu:tiny_backbone", "--clips", str(clips), "--out", str(tmp_path / "c3"),
+                   "--batch", "3", "--device", "cpu"]) == 0
+    assert torch.equal(FeatureCache(str(tmp_path / "c3"))[4], cache[4])
