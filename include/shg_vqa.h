@@ -108,6 +108,16 @@ int shg_weighted_ce_bwd(const void* logits, int dtype, int64_t rows, int n_class
 int shg_bce_logits_fwd_bwd(const void* logits, int dtype, int64_t rows, int n_classes, const float* target,
                            const float* gscale, float* loss, void* dlogits, int64_t ldd, void* stream);
 
+/* The step's scalar loss arithmetic in one launch each way (agqaHGQA.py:344-378):
+ *   total[0] = bce[0] * bce_scale + rel_sums[0] / rel_sums[1] + act_sums[0] / act_sums[1]
+ *   diag[5]  = { bce, rel CE, act CE, rel class error %, act class error % }   (class error = 100 - 100 * sums[2] / max(sums[3], 1))
+ * rel_sums / act_sums are the [4] outputs of shg_weighted_ce_fwd (after the data-parallel all-reduce, if any).
+ * bwd: d_total [1] (NULL = 1) -> d_rel_sums [4], d_act_sums [4] (numerator and denominator slots), d_bce [1]. */
+int shg_loss_combine_fwd(const float* rel_sums, const float* act_sums, const float* bce, float bce_scale, float* total,
+                         float* diag, void* stream);
+int shg_loss_combine_bwd(const float* d_total, const float* rel_sums, const float* act_sums, float bce_scale,
+                         float* d_rel_sums, float* d_act_sums, float* d_bce, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused epilogues.
  * y = act(x + bias), optional dropout.  Replaces BertIntermediate's bias+erf-GELU

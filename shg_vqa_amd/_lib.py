@@ -26,6 +26,8 @@ _SIGNATURES = {
     "shg_weighted_ce_fwd": ([P, I, L, I, P, P, L, P, P, P], c_int),
     "shg_weighted_ce_bwd": ([P, I, L, I, P, P, P, P, P, P, L, P], c_int),
     "shg_bce_logits_fwd_bwd": ([P, I, L, I, P, P, P, P, L, P], c_int),
+    "shg_loss_combine_fwd": ([P, P, P, F, P, P, P], c_int),
+    "shg_loss_combine_bwd": ([P, P, P, F, P, P, P, P], c_int),
     "shg_bias_act_fwd": ([P, P, P, I, L, I, I, F, P, U, P], c_int),
     "shg_bias_act_bwd": ([P, P, P, P, P, I, I, L, I, I, F, P, U, P], c_int),
     "shg_bias_act_drop_res_ln_fwd": ([P, P, P, P, P, P, P, P, P, I, L, I, I, F, F, P, U, P], c_int),

@@ -181,12 +181,17 @@ class AGQA:
             br_r.join(rs, rgrid, rq, rt, as_, agrid, aq, at, rel_logit, act_logit)
             if self.world is not None:
                 rs, as_ = self.world.global_loss_sums2(rs, as_)
-            rel_ce, act_ce = rs[0] / rs[1], as_[0] / as_[1]
             # data parallel: CE terms are already global (their gradient sums to the global gradient);
-            # the BCE mean is local, so it enters with 1/world (ddp.py)
-            total = bce.sum() * (self.world.bce_scale() if self.world is not None else 1.0) + rel_ce + act_ce
-            return dict(total=total, bce=bce.sum().detach(), rel_ce=rel_ce.detach(), act_ce=act_ce.detach(),
-                        rel_err=100.0 - 100.0 * rs[2] / rs[3].clamp(min=1), act_err=100.0 - 100.0 * as_[2] / as_[3].clamp(min=1),
+            # the BCE mean is local, so it enters with 1/world (ddp.py).  total = bce * scale + rel CE + act CE
+            scale = self.world.bce_scale() if self.world is not None else 1.0
+            if os.environ.get("SHG_LOSS_COMBINE", "1") == "0":        # the same arithmetic as ~40 one-thread torch kernels (A/B)
+                rel_ce, act_ce = rs[0] / rs[1], as_[0] / as_[1]
+                total = bce.sum() * scale + rel_ce + act_ce
+                diag = (bce.sum().detach(), rel_ce.detach(), act_ce.detach(), 100.0 - 100.0 * rs[2] / rs[3].clamp(min=1),
+                        100.0 - 100.0 * as_[2] / as_[3].clamp(min=1))
+            else:
+                total, diag = ops.combine_losses(rs, as_, bce, scale)
+            return dict(total=total, bce=diag[0], rel_ce=diag[1], act_ce=diag[2], rel_err=diag[3], act_err=diag[4],
                         logit=logit, hg_logit=hg_logit, rel_logit=rel_logit, act_logit=act_logit,
                         rel_idx=(rq, rt), act_idx=(aq, at), rel_grid=rgrid, act_grid=agrid)
         if a.task_vqa:

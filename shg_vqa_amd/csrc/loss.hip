@@ -108,6 +108,27 @@ __global__ __launch_bounds__(256) void bce_kernel(const T* __restrict__ logits, 
     if (threadIdx.x == 0 && loss) loss[0] = (float)(sh[0] / (double)rows);   // = C * mean over rows*C
 }
 
+// total = bce * bce_scale + rel[0] / rel[1] + act[0] / act[1] and the step's reported scalars in ONE launch (and one for the
+// gradients): as torch scalar arithmetic this was 14 forward and ~24 backward kernels of one thread each between the end of the
+// forward pass and the first kernel of backward - a strictly serial stretch of the step.
+__global__ void loss_combine_fwd_kernel(const float* __restrict__ rel, const float* __restrict__ act, const float* __restrict__ bce,
+                                        float bce_scale, float* __restrict__ total, float* __restrict__ diag) {
+    const float rel_ce = rel[0] / rel[1], act_ce = act[0] / act[1];
+    total[0] = bce[0] * bce_scale + rel_ce + act_ce;
+    diag[0] = bce[0];
+    diag[1] = rel_ce;
+    diag[2] = act_ce;
+    diag[3] = 100.f - 100.f * rel[2] / fmaxf(rel[3], 1.f);      // class error of the matched slots (agqaHGQA.py:221-229)
+    diag[4] = 100.f - 100.f * act[2] / fmaxf(act[3], 1.f);
+}
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ g, const float* __restrict__ rel, const float* __restrict__ act,
+                                        float bce_scale, float* __restrict__ d_rel, float* __restrict__ d_act, float* __restrict__ d_bce) {
+    const float gt = g ? g[0] : 1.f;
+    d_rel[0] = gt / rel[1]; d_rel[1] = -gt * rel[0] / (rel[1] * rel[1]); d_rel[2] = 0.f; d_rel[3] = 0.f;
+    d_act[0] = gt / act[1]; d_act[1] = -gt * act[0] / (act[1] * act[1]); d_act[2] = 0.f; d_act[3] = 0.f;
+    d_bce[0] = gt * bce_scale;
+}
+
 }  // namespace shg
 
 using namespace shg;
@@ -155,4 +176,19 @@ extern "C" int shg_bce_logits_fwd_bwd(const void* logits, int dtype, int64_t row
         hipLaunchKernelGGL(bce_kernel<bf16_t>, dim3(1), dim3(256), 0, st, (const bf16_t*)logits, n, rows, n_classes, target, gscale, loss, (bf16_t*)dlogits, ldd);
     else return fail_arg("bce: bad dtype");
     return check_launch("bce_logits");
+}
+
+extern "C" int shg_loss_combine_fwd(const float* rel_sums, const float* act_sums, const float* bce, float bce_scale, float* total,
+                                    float* diag, void* stream) {
+    if (!rel_sums || !act_sums || !bce || !total || !diag) return shg::fail_arg("loss_combine_fwd: null pointer");
+    hipLaunchKernelGGL(shg::loss_combine_fwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rel_sums, act_sums, bce, bce_scale, total, diag);
+    return shg::check_launch("loss_combine_fwd");
+}
+
+extern "C" int shg_loss_combine_bwd(const float* d_total, const float* rel_sums, const float* act_sums, float bce_scale,
+                                    float* d_rel_sums, float* d_act_sums, float* d_bce, void* stream) {
+    if (!rel_sums || !act_sums || !d_rel_sums || !d_act_sums || !d_bce) return shg::fail_arg("loss_combine_bwd: null pointer");
+    hipLaunchKernelGGL(shg::loss_combine_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_total, rel_sums, act_sums, bce_scale,
+                       d_rel_sums, d_act_sums, d_bce);
+    return shg::check_launch("loss_combine_bwd");
 }

@@ -120,6 +120,30 @@ def bce_logits(logits, target, gscale=None, want_grad=True, padded=False):
     return loss, d
 
 
+def loss_combine_fwd(rel_sums, act_sums, bce, bce_scale):
+    """-> (total [1], diag [5] = bce, rel CE, act CE, rel class error %, act class error %)."""
+    _dev(rel_sums, act_sums, bce)
+    for t in (rel_sums, act_sums):
+        _need(t.dtype == torch.float32 and t.numel() == 4 and t.is_contiguous(), "loss sums must be contiguous fp32 [4]")
+    _need(bce.dtype == torch.float32 and bce.numel() == 1, "bce must be fp32 [1]")
+    total = torch.empty(1, dtype=torch.float32, device=bce.device)
+    diag = torch.empty(5, dtype=torch.float32, device=bce.device)
+    _lib.call("shg_loss_combine_fwd", rel_sums.data_ptr(), act_sums.data_ptr(), bce.data_ptr(), float(bce_scale), total.data_ptr(),
+              diag.data_ptr(), _stream())
+    return total, diag
+
+
+def loss_combine_bwd(d_total, rel_sums, act_sums, bce_scale):
+    """-> (d_rel_sums [4], d_act_sums [4], d_bce [1])."""
+    _dev(d_total, rel_sums, act_sums)
+    out = torch.empty(9, dtype=torch.float32, device=rel_sums.device)
+    if d_total is not None:
+        _need(d_total.dtype == torch.float32 and d_total.numel() == 1, "d_total must be fp32 [1]")
+    _lib.call("shg_loss_combine_bwd", _p(d_total), rel_sums.data_ptr(), act_sums.data_ptr(), float(bce_scale), out.data_ptr(),
+              out[4:].data_ptr(), out[8:].data_ptr(), _stream())
+    return out[:4], out[4:8], out[8:]
+
+
 # ------------------------------------------------------------------------------------------------
 def _rows_cols(x):
     _need(x.is_contiguous() and x.dim() >= 2, "activation must be contiguous with >= 2 dims")

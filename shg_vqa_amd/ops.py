@@ -656,6 +656,33 @@ def bce_with_logits_times_c(logits, target):
     return _BCELoss.apply(logits, target)
 
 
+class _CombineLosses(torch.autograd.Function):
+    """total = bce * scale + rel_sums[0] / rel_sums[1] + act_sums[0] / act_sums[1] (agqaHGQA.py:344-378) and the reported
+    scalars, one kernel forward and one backward instead of ~40 single-thread torch kernels between the forward pass and the
+    first kernel of backward."""
+
+    @staticmethod
+    def forward(ctx, rel_sums, act_sums, bce, scale):
+        rs, as_, b = rel_sums.contiguous(), act_sums.contiguous(), bce.reshape(1).contiguous()
+        total, diag = K.loss_combine_fwd(rs, as_, b, scale)
+        ctx.save_for_backward(rs, as_)
+        ctx.scale = float(scale)
+        ctx.bce_shape = bce.shape
+        ctx.mark_non_differentiable(diag)
+        return total.view(()), diag
+
+    @staticmethod
+    def backward(ctx, g, _):
+        rs, as_ = ctx.saved_tensors
+        d_rel, d_act, d_bce = K.loss_combine_bwd(None if g is None else g.reshape(1).float().contiguous(), rs, as_, ctx.scale)
+        return d_rel, d_act, d_bce.view(ctx.bce_shape), None
+
+
+def combine_losses(rel_sums, act_sums, bce, scale=1.0):
+    """-> (total [], diag [5] = bce, rel CE, act CE, rel class error %, act class error %)."""
+    return _CombineLosses.apply(rel_sums, act_sums, bce, scale)
+
+
 # ------------------------------------------------------------------------------------------------
 class ParamSlice:
     """Rows r0:r1 of a parameter (e.g. the q/k/v blocks of nn.MultiheadAttention.in_proj_weight,

@@ -999,3 +999,29 @@ def test_wgrad_group_is_exact_on_integer_data_and_handles_mixed_problem_lists(K)
     K.wgrad_group(f32)
     for (dy, x, gw), r in zip(f32, ref):
         assert torch.equal(gw, r)
+
+
+def test_loss_combine_matches_torch_autograd():
+    """shg_loss_combine_fwd / bwd (agqaHGQA.py:344-378): total = bce * scale + rel[0] / rel[1] + act[0] / act[1], the reported
+    scalars, and the gradients torch's autograd gives for the same expression."""
+    from shg_vqa_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for scale in (1.0, 0.25):
+        rel = (torch.rand(4, generator=gen) * 50 + 1).to(DEV).requires_grad_(True)
+        act = (torch.rand(4, generator=gen) * 50 + 1).to(DEV).requires_grad_(True)
+        with torch.no_grad():
+            act[3] = 0.0                                     # no matched slot: class error 100 - 100 * x / max(0, 1)
+        bce = (torch.rand(1, generator=gen) * 100).to(DEV).requires_grad_(True)
+        total, diag = ops.combine_losses(rel, act, bce, scale)
+        (total * 3.0).backward()
+        got = [t.grad.clone() for t in (rel, act, bce)]
+        for t in (rel, act, bce):
+            t.grad = None
+        ref = bce.sum() * scale + rel[0] / rel[1] + act[0] / act[1]
+        (ref * 3.0).backward()
+        assert torch.allclose(total, ref, rtol=1e-6)
+        for a, b in zip(got, (rel.grad, act.grad, bce.grad)):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (a, b)
+        exp = torch.stack([bce.detach().sum(), rel[0] / rel[1], act[0] / act[1], 100.0 - 100.0 * rel[2] / rel[3].clamp(min=1),
+                           100.0 - 100.0 * act[2] / act[3].clamp(min=1)]).detach()
+        assert torch.allclose(diag, exp, rtol=1e-6)
