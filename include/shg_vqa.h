@@ -130,6 +130,15 @@ int shg_bias_act_fwd(const void* x, const float* bias, void* y, int dtype, int64
 int shg_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial,
                      int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
                      const uint64_t* seed_state, uint64_t stream_id, void* stream);
+/* The same with two views (the conv stack's backward, modeling_capsbert.py:991-996 / :1037-1073 run in reverse):
+ *   dy is read from groups of dy_group_stride rows, skipping the first dy_row_offset rows of every group and taking
+ *   dy_rows_per_group (the token gradients [B, 1 + 392, C] without the cls rows; dy_rows_per_group == 0: plain [rows, cols]);
+ *   dx2 (optional, same dtype) receives a second copy of the result, row r at row dx2_rows[r] (int32 table; NULL: r) - the
+ *   zero-bordered layout the input-gradient convolution gathers from. */
+int shg_bias_act_bwd_view(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial, int n_partials,
+                          int dtype, int64_t rows, int cols, int act, float p_drop, const uint64_t* seed_state,
+                          uint64_t stream_id, int64_t dy_rows_per_group, int64_t dy_group_stride, int64_t dy_row_offset,
+                          void* dx2, const int32_t* dx2_rows, void* stream);
 
 /* z = dropout(act(x + bias)) + residual;  y = LayerNorm(z) * gamma + beta.
  * Replaces BertAttOutput / BertOutput (modeling_capsbert.py:431-435, :485-489), the decoder's

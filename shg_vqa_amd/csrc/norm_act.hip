@@ -266,12 +266,21 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__
     }
 }
 
+// Optional views of bias_act_bwd (the conv stack's backward, ops._VisualConvTokens): the incoming gradient read from every
+// group of `dy_group_stride` rows skipping the first `dy_row_offset` (the token gradients [B, 1 + 392, C] without the cls
+// rows - no contiguous copy), and a second copy of the result scattered by a row table into a zero-bordered buffer (the padded
+// layout the input-gradient convolution gathers from - no F.pad pass).
+struct BwdView {
+    int64_t dy_rows_per_group, dy_group_stride, dy_row_offset;      // rows_per_group == 0: dy is [rows, cols] as it is
+    void* dx2;                                                      // second output (same dtype) or null
+    const int32_t* row2;                                            // its row of result row r (null: r)
+};
 template <typename T, int ACT, int NCH, bool DROP>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                            const T* __restrict__ dy, T* __restrict__ dx,
                                                            float* __restrict__ dbias_p, int64_t rows, int cols,
                                                            uint32_t drop_thr, float drop_scale,
-                                                           const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
+                                                           const uint64_t* __restrict__ seed_state, uint64_t stream_id, BwdView vw) {
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float red[];   // [4][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -289,13 +298,17 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
         if (lane + i * 64 < nchunk) load_param_vec<V>(bias, (lane + i * 64) * V, bsv[i]);
     }
     for (int64_t row = r_begin + wave; row < r_end; row += 4) {
+        const int64_t dy_row = vw.dy_rows_per_group > 0
+                                   ? (row / vw.dy_rows_per_group) * vw.dy_group_stride + vw.dy_row_offset + row % vw.dy_rows_per_group
+                                   : row;
+        const int64_t row2 = vw.row2 ? (int64_t)vw.row2[row] : row;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + i * 64;
             if (ch < nchunk) {
                 const int c0 = ch * V;
                 const int64_t off = row * cols + c0;
-                Vec16<T> xv = load16(x + off), gv = load16(dy + off), dv;
+                Vec16<T> xv = load16(x + off), gv = load16(dy + dy_row * cols + c0), dv;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     float d = gv.get(j);
@@ -305,6 +318,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
                     ab[i][j] += to_f32(from_f32<T>(d));
                 }
                 store16(dx + off, dv);
+                if (vw.dx2) store16(reinterpret_cast<T*>(vw.dx2) + row2 * cols + c0, dv);
             }
         }
     }
@@ -730,10 +744,15 @@ extern "C" int shg_bias_act_fwd(const void* x, const float* bias, void* y, int d
     return check_launch("bias_act_fwd");
 }
 
-extern "C" int shg_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial,
-                                int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
-                                const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+extern "C" int shg_bias_act_bwd_view(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial,
+                                     int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
+                                     const uint64_t* seed_state, uint64_t stream_id, int64_t dy_rows_per_group,
+                                     int64_t dy_group_stride, int64_t dy_row_offset, void* dx2, const int32_t* dx2_rows, void* stream) {
     if (!x || !dy || !dx) return fail_arg("bias_act_bwd: null pointer");
+    if (dy_rows_per_group < 0 || (dy_rows_per_group > 0 && (dy_row_offset < 0 || dy_group_stride < dy_rows_per_group + dy_row_offset)))
+        return fail_arg("bias_act_bwd: bad view of dy");
+    if (dx2 && (reinterpret_cast<uintptr_t>(dx2) & 15)) return fail_arg("bias_act_bwd: dx2 must be 16-byte aligned");
+    const BwdView vw{dy_rows_per_group, dy_group_stride, dy_row_offset, dx2, dx2_rows};
     if (int e = check_cols(dtype, cols, "bias_act_bwd: unsupported cols", 16)) return e;
     if (n_partials < 1 || n_partials > MAX_PARTIALS) return fail_arg("bias_act_bwd: bad n_partials");
     if (rows <= 0) return rows == 0 ? 0 : fail_arg("bias_act_bwd: negative rows");
@@ -744,7 +763,7 @@ extern "C" int shg_bias_act_bwd(const void* x, const float* bias, const void* dy
     hipStream_t st = (hipStream_t)stream;
     const int nch = (cols / (dtype == SHG_BF16 ? 8 : 4) + 63) / 64;
     if (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return fail_arg("bias_act_bwd: bias must be 16-byte aligned");
-#define BA_BWD3(T, ACT, NCH, DROP) hipLaunchKernelGGL((bias_act_bwd_kernel<T, ACT, NCH, DROP>), grid, block, lds, st, (const T*)x, bias, (const T*)dy, (T*)dx, dbias_partial, rows, cols, thr, scale, seed_state, stream_id)
+#define BA_BWD3(T, ACT, NCH, DROP) hipLaunchKernelGGL((bias_act_bwd_kernel<T, ACT, NCH, DROP>), grid, block, lds, st, (const T*)x, bias, (const T*)dy, (T*)dx, dbias_partial, rows, cols, thr, scale, seed_state, stream_id, vw)
 #define BA_BWD2(T, ACT, NCH) do { if (thr) BA_BWD3(T, ACT, NCH, true); else BA_BWD3(T, ACT, NCH, false); } while (0)
 #define BA_BWD(T, ACT) do { if (nch <= 2) BA_BWD2(T, ACT, 2); else if (nch <= 4) BA_BWD2(T, ACT, 4); else if (nch <= 8) BA_BWD2(T, ACT, 8); else BA_BWD2(T, ACT, 16); } while (0)
     if (dtype == SHG_F32) { if (act == 0) BA_BWD(float, 0); else if (act == 1) BA_BWD(float, 1); else BA_BWD(float, 2); }
@@ -753,4 +772,11 @@ extern "C" int shg_bias_act_bwd(const void* x, const float* bias, const void* dy
 #undef BA_BWD2
 #undef BA_BWD3
     return check_launch("bias_act_bwd");
+}
+
+extern "C" int shg_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial,
+                                int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
+                                const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+    return shg_bias_act_bwd_view(x, bias, dy, dx, dbias_partial, n_partials, dtype, rows, cols, act, p_drop, seed_state, stream_id, 0, 0,
+                                 0, nullptr, nullptr, stream);
 }

@@ -82,9 +82,20 @@ def convert_relations_to_features_test(rel_trplts_tokens, num_rel=8, num_situati
     return [InputFeatures(None, None, seg.copy(), None) for _ in range(bsize)]
 
 
+_SEGMENT_IDS = {}
+
+
 def frame_segment_ids(batch, num_situations, per_frame, device):
-    """Vectorised form of the segment ids above: [B, num_situations * per_frame] int64 on `device`."""
-    return torch.arange(num_situations, device=device).repeat_interleave(per_frame).unsqueeze(0).expand(batch, -1).contiguous()
+    """Vectorised form of the segment ids above: [B, num_situations * per_frame] int64 on `device`.  A constant of the shape:
+    built once per (shape, device) - three tiny kernels per call otherwise, at the very start of every step (read-only)."""
+    key = (int(batch), int(num_situations), int(per_frame), str(device))
+    capturing = torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+    t = None if capturing else _SEGMENT_IDS.get(key)            # (a captured step builds its own: graph-private memory)
+    if t is None:
+        t = torch.arange(num_situations, device=device).repeat_interleave(per_frame).unsqueeze(0).expand(batch, -1).contiguous()
+        if not capturing:
+            _SEGMENT_IDS[key] = t
+    return t
 
 
 def clip_targets_device(triplets, lengths):

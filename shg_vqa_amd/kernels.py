@@ -202,16 +202,31 @@ def bias_act_fwd(x, bias, act, p_drop=0.0, seed_state=None, stream_id=0):
     return y
 
 
-def bias_act_bwd(x, bias, dy, act, p_drop=0.0, seed_state=None, stream_id=0, want_dbias=True):
-    """-> (dx, dbias_partial [n_partials, cols] or None)."""
+def bias_act_bwd(x, bias, dy, act, p_drop=0.0, seed_state=None, stream_id=0, want_dbias=True, dy_groups=None, out2=None):
+    """-> (dx, dbias_partial [n_partials, cols] or None).
+    dy_groups = (rows_per_group, group_stride, row_offset): dy is a contiguous [groups * group_stride, cols] tensor of which every
+    group contributes rows row_offset .. row_offset + rows_per_group (shg_bias_act_bwd_view); out2 = (buffer, int32 row table):
+    a second copy of dx, row r at buffer row table[r]."""
     _dev(x, bias, dy, seed_state)
     rows, cols = _rows_cols(x)
-    _need(dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous(), "dy must match x")
+    if dy_groups is None:
+        _need(dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous(), "dy must match x")
+        rpg = gs = off = 0
+    else:
+        rpg, gs, off = (int(v) for v in dy_groups)
+        _need(dy.dtype == x.dtype and dy.is_contiguous() and dy.shape[-1] == cols and rpg > 0 and rows % rpg == 0 and gs >= rpg + off >= rpg
+              and dy.numel() == rows // rpg * gs * cols, "dy view does not fit")
     dx = torch.empty_like(x)
     npart = colsum_partials(rows)
     part = torch.empty((npart, cols), dtype=torch.float32, device=x.device) if want_dbias else None
-    _lib.call("shg_bias_act_bwd", x.data_ptr(), _p(bias), dy.data_ptr(), dx.data_ptr(), _p(part), npart, _dt(x), rows,
-              cols, act, float(p_drop), _p(seed_state), int(stream_id), _stream())
+    buf2 = tbl2 = None
+    if out2 is not None:
+        buf2, tbl2 = out2
+        _dev(buf2, tbl2)
+        _need(buf2.dtype == x.dtype and buf2.is_contiguous() and buf2.shape[-1] == cols, "out2 buffer must be contiguous [.., cols] of x's dtype")
+        _need(tbl2.dtype == torch.int32 and tbl2.numel() == rows and tbl2.is_contiguous(), "out2 row table must be int32 [rows]")
+    _lib.call("shg_bias_act_bwd_view", x.data_ptr(), _p(bias), dy.data_ptr(), dx.data_ptr(), _p(part), npart, _dt(x), rows,
+              cols, act, float(p_drop), _p(seed_state), int(stream_id), rpg, gs, off, _p(buf2), _p(tbl2), _stream())
     return dx, part
 
 

@@ -455,6 +455,23 @@ def conv1_forward(feat, w1, b1, bufs=None):
     return x_cl, y1p, pre1
 
 
+def _padded_grad_buffer(E, B, To, H, W, C, dtype, device):
+    """(buffer [B, To + 8, H + 2, W + 2, C] with a zero border, int32 row table [B * To * H * W]): where conv2's output gradient
+    lives for the input-gradient convolution (dy padded by 4 in T and 1 in H / W, include/shg_vqa.h).  One per shape, reused every
+    step: only the interior is ever written, and the convolution that reads it is enqueued before the next step's writer."""
+    key = (B, To, H, W, C, dtype, str(device))
+    cache = E.__dict__.setdefault("_d2p_bufs", {})
+    hit = cache.get(key)
+    if hit is None:
+        cache.clear()
+        buf = torch.zeros((B, To + 8, H + 2, W + 2, C), dtype=dtype, device=device)
+        m = torch.arange(B * To * H * W, device=device)
+        w_, h_, t_, b_ = m % W, (m // W) % H, (m // (W * H)) % To, m // (W * H * To)
+        rows = (((b_ * (To + 8) + t_ + 4) * (H + 2) + h_ + 1) * (W + 2) + w_ + 1).to(torch.int32).contiguous()
+        hit = cache[key] = (buf, rows)
+    return hit
+
+
 class _VisualConvTokens(torch.autograd.Function):
     """Second conv + token assembly of VisualFeatEncoder (mc:991-996, :1037-1073) and the backward of
     BOTH convolutions: conv(5,3,3) 768->768 + bias + GELU -> tokens [B, 392, C] in (t,h,w) order,
@@ -495,15 +512,24 @@ class _VisualConvTokens(torch.autograd.Function):
             E.grad_written(pe)
         if cls_token._shg_grad is not None:
             E.grad_written(cls_token)
-        d_tok = d_out[:, 1:].contiguous().view(pre2.shape)
-        # conv2: GELU', bias grad, weight grad, input grad
-        d2, part = K.bias_act_bwd(pre2, None, d_tok, ACT_GELU, want_dbias=True)
+        # conv2: GELU', bias grad, weight grad, input grad.  One kernel reads the token gradients without their cls rows (no
+        # contiguous copy) and writes d2 twice: dense (the weight gradient's operand) and into the zero-bordered layout the
+        # input-gradient convolution gathers from (no F.pad pass) - a persistent buffer whose border stays zero.
+        To, H, W = pre2.shape[1], pre2.shape[2], pre2.shape[3]
+        fused = d_out.is_contiguous() and not torch.cuda.is_current_stream_capturing() and os.environ.get("SHG_CONV_BWD_FUSED", "1") != "0"
+        if fused:
+            d2p, rows2 = _padded_grad_buffer(E, B, To, H, W, C, pre2.dtype, d_out.device)
+            d2, part = K.bias_act_bwd(pre2, None, d_out, ACT_GELU, want_dbias=True, dy_groups=(n_tok - 1, n_tok, 1), out2=(d2p, rows2))
+        else:
+            d_tok = d_out[:, 1:].contiguous().view(pre2.shape)
+            d2, part = K.bias_act_bwd(pre2, None, d_tok, ACT_GELU, want_dbias=True)
         _acc_vec(part, b2)
         # input gradient of conv2 = the forward gather over dy padded by (4 in T, 1 in H/W); the kernel reads
         # the weight flipped / transposed in place.  It is issued BEFORE conv2's weight gradient: both fill the chip,
         # and only the input gradient is on the critical path (-> d1 -> conv1's weight gradient, the last kernel
         # of backward), so the side stream's conv2 wgrad waits for it instead of sharing the CUs with it.
-        d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
+        if not fused:
+            d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
         d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2))
         # The conv weight gradients are the last kernels of backward and fill the chip.  They stay on THIS stream:
         # behind the weight-gradient stream's backlog of small split-K GEMMs (it runs ~2 ms late at this point)
