@@ -298,6 +298,19 @@ __device__ __forceinline__ float act_grad_rt(float u, int act, bool fast) {
 constexpr int STG_LD = 68;                         // fp32 row stride of the epilogue staging tile (64 + 4 pad)
 constexpr int STG_BYTES = 4 * 64 * STG_LD * 4;     // one 64 x 64 staging tile per wave
 
+// Compile-time forms for the row writers: with the run-time `act` inside their unrolled element loops the compiler emitted a
+// scalar compare + branch per ELEMENT (292 compares / ~600 branches in the epilogue of one instantiation - 8 us of the 14 us an
+// epilogue cost per round of tiles, against 2 us for its global stores); RowWriter::run now switches ONCE per call.
+template <int ACT, bool FAST> __device__ __forceinline__ float act_ct(float x) {
+    if (ACT == SHG_ACT_GELU) return FAST ? gelu_fast(x) : gelu_erf(x);
+    if (ACT == SHG_ACT_RELU) return fmaxf(x, 0.f);
+    return x;
+}
+template <int ACT, bool FAST> __device__ __forceinline__ float act_grad_ct(float u) {
+    if (ACT == SHG_ACT_GELU) return FAST ? gelu_fast_grad(u) : gelu_erf_grad(u);
+    if (ACT == SHG_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
 template <bool FAST = false> __device__ __forceinline__ float apply_act(float x, int act) {
     if (act == SHG_ACT_GELU) return FAST ? gelu_fast(x) : gelu_erf(x);
     if (act == SHG_ACT_RELU) return fmaxf(x, 0.f);
@@ -312,7 +325,15 @@ template <> struct RowWriter<bf16_t> {
     // of going to memory; the caller flushes them once with flush_csum (fewer atomics on the shared bias-gradient vector)
     __device__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0, float* csum_carry = nullptr) {
+        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        else run_act<SHG_ACT_NONE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+    }
+    template <int ACT>
+    __device__ static void run_act(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
+                                   int64_t N, int lane, int gap, float* csum_carry) {
         float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool drop = ep.drop_thr != 0;
         const uint64_t dseed = ep.drop_thr ? dropout_seed(ep.seed_state, ep.stream_id) : 0;
         // a lane keeps its 8 columns through all 8 row passes: their bias is loaded once, ahead of the loop (per-element
         // loads inside it were 8 dependent L2 round trips per pass: 15 us of a 50 us 8192 x 2048 x 768 launch)
@@ -331,6 +352,29 @@ template <> struct RowWriter<bf16_t> {
                     if (r < nv) bias8[r] = ep.bias[n + r];
             }
         }
+        // the plain case (bias + activation, whole 16-byte vectors, all 64 rows inside the matrix): the eight passes' LDS reads
+        // are issued together and nothing but the activation sits between them and the stores
+        if (!ep.gpre && !ep.csum && !ep.accumulate && !drop && !ep.pre && !ep.crow && ep.vec_ok && nv == 8 && mbase + 64 <= M) {
+            f32x4 va[8], vb[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int row = 8 * p + (lane >> 3);
+                va[p] = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
+                vb[p] = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col + 4);
+            }
+            bf16_t* dst0 = ep.c + (mbase + (lane >> 3)) * ep.ldc + n;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = (bf16_t)act_ct<ACT, true>(va[p][r] + bias8[r]);
+                    o[4 + r] = (bf16_t)act_ct<ACT, true>(vb[p][r] + bias8[4 + r]);
+                }
+                *reinterpret_cast<bf16x8*>(dst0 + (int64_t)(8 * p) * ep.ldc) = o;
+            }
+            return;
+        }
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
             const int row = 8 * p + (lane >> 3);
@@ -346,10 +390,13 @@ template <> struct RowWriter<bf16_t> {
             if (ep.gpre) {                               // (nv == 8: N % 8 == 0 is checked on the host)
                 const bf16x8 gp = *reinterpret_cast<const bf16x8*>(ep.gpre + m * N + n);
                 bf16x8 o;
+                if (drop) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    if (ep.drop_thr) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
-                    u[r] *= act_grad_rt((float)gp[r], ep.act, true);
+                    u[r] *= act_grad_ct<ACT, true>((float)gp[r]);
                     o[r] = (bf16_t)u[r];
                     csum8[r] += (float)o[r];
                 }
@@ -361,16 +408,16 @@ template <> struct RowWriter<bf16_t> {
                 if (ep.accumulate) {                       // C += A.B in fp32, rounded once (residual-gradient sums)
                     const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(apply_act<true>(u[r], ep.act) + (float)old[r]);
-                } else if (ep.drop_thr) {
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(act_ct<ACT, true>(u[r]) + (float)old[r]);
+                } else if (drop) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
-                        const float a = apply_act<true>(u[r], ep.act);
+                        const float a = act_ct<ACT, true>(u[r]);
                         o[r] = (bf16_t)(dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? a * ep.drop_scale : 0.f);
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)apply_act<true>(u[r], ep.act);
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)act_ct<ACT, true>(u[r]);
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) q[r] = (bf16_t)u[r];
@@ -378,7 +425,7 @@ template <> struct RowWriter<bf16_t> {
                 if (pre) *reinterpret_cast<bf16x8*>(pre) = q;
             } else {
                 for (int r = 0; r < nv; ++r) {
-                    const float x = apply_act<true>(u[r], ep.act);
+                    const float x = act_ct<ACT, true>(u[r]);
                     dst[r] = (bf16_t)(ep.accumulate ? x + (float)dst[r] : x);
                     if (pre) pre[r] = (bf16_t)u[r];
                 }
@@ -415,6 +462,14 @@ template <> struct RowWriter<float> {
     __device__ static void flush_csum(float*, const Epilogue<float>&, int64_t, int64_t, int, int = 0) {}
     __device__ static void run(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0, float* /*csum_carry: fp32 outputs flush per piece*/ = nullptr) {
+        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU>(stage, ep, mbase, nbase, M, N, lane, gap);
+        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU>(stage, ep, mbase, nbase, M, N, lane, gap);
+        else run_act<SHG_ACT_NONE>(stage, ep, mbase, nbase, M, N, lane, gap);
+    }
+    template <int ACT>
+    __device__ static void run_act(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
+                                   int64_t N, int lane, int gap) {
+        const bool drop = ep.drop_thr != 0;
         if (ep.atomic) {                               // one 256-byte row segment per wave instruction
             const int64_t n = nbase + lane + (lane >= 32 ? gap : 0);
             for (int row = 0; row < 64; ++row) {
@@ -446,18 +501,21 @@ template <> struct RowWriter<float> {
             float* pre = ep.pre ? ep.pre + m * N + n : nullptr;
             if (ep.gpre) {                               // (N % 8 == 0 is checked on the host)
                 const f32x4 gp = *reinterpret_cast<const f32x4*>(ep.gpre + m * N + n);
+                if (drop) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (ep.drop_thr) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
-                    u[r] *= act_grad_rt(gp[r], ep.act, false);
+                    u[r] *= act_grad_ct<ACT, false>(gp[r]);
                     csum4[r] += u[r];
                 }
                 *reinterpret_cast<f32x4*>(dst) = f32x4{u[0], u[1], u[2], u[3]};
                 continue;
             }
             if (nv == 4 && ep.vec_ok) {
-                f32x4 o = {apply_act(u[0], ep.act), apply_act(u[1], ep.act), apply_act(u[2], ep.act), apply_act(u[3], ep.act)};
-                if (ep.drop_thr) {
+                f32x4 o = {act_ct<ACT, false>(u[0]), act_ct<ACT, false>(u[1]), act_ct<ACT, false>(u[2]), act_ct<ACT, false>(u[3])};
+                if (drop) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         o[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? o[r] * ep.drop_scale : 0.f;
@@ -468,7 +526,7 @@ template <> struct RowWriter<float> {
                 else if (pre) for (int r = 0; r < 4; ++r) pre[r] = u[r];
             } else {
                 for (int r = 0; r < nv; ++r) {
-                    const float x = apply_act(u[r], ep.act);
+                    const float x = act_ct<ACT, false>(u[r]);
                     dst[r] = ep.accumulate ? dst[r] + x : x;
                     if (pre) pre[r] = u[r];
                 }
