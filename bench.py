@@ -27,7 +27,9 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 TRAIN_GFLOP_PER_QA = 428.21        # fwd + required bwd GEMM-like work per QA pair (HGQA)
+TRAIN_GFLOP_PER_QA_VQA = 365.40    # same table, --taskVQA (BASELINE.json configs[1]: no HG decoder / no Hungarian; the x-layers train)
 FWD_GFLOP_PER_QA = 178.79          # same table: forward only
+FWD_GFLOP_PER_QA_VQA = 149.55
 STACK_FWD_GFLOP_PER_QA = 45.50     # same table: the attention stack alone (5 l-layers S=40, 5 r-layers S=393, 2 x-layers 40<->393)
 
 
@@ -43,7 +45,7 @@ def synthetic_device_batches(n_batches, bsz, seed, device):
     return out
 
 
-def cpu_baseline(bsz=4, timed=4):
+def cpu_baseline(bsz=4, timed=4, task="hgqa"):
     """The CPU oracle's full train step (same arithmetic, fp32, dropout on) on this box's host cores."""
     from oracle import shg_ref
     # the box's CPU share, not the host's core count (oversubscribing the cgroup makes MKL crawl)
@@ -52,7 +54,7 @@ def cpu_baseline(bsz=4, timed=4):
     except AttributeError:
         ncpu = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(ncpu, 16)))
-    cfg = shg_ref.Cfg()
+    cfg = shg_ref.Cfg() if task == "hgqa" else shg_ref.Cfg(task=task)
     p = shg_ref.det_params(cfg, requires_grad=True)
     state = {}
     times = []
@@ -68,7 +70,7 @@ def cpu_baseline(bsz=4, timed=4):
                       "(%.1f s/step)" % (bsz, timed, per)}
 
 
-def forward_only(trainer, batches, iters=10):
+def forward_only(trainer, batches, iters=10, fwd_gflop=FWD_GFLOP_PER_QA):
     """SURVEY 8(d) "forward-only QA-pairs/s": the predict() pass (eval mode, no autograd graph, same kernels)."""
     from shg_vqa_amd.engine import engine
     E = engine()
@@ -88,7 +90,7 @@ def forward_only(trainer, batches, iters=10):
     bsz = batches[0]["input_ids"].shape[0]
     qa = bsz / per
     return {"value": round(qa, 1), "unit": "QA-pairs/s", "ms_per_batch": round(1e3 * per, 3),
-            "mfma_frac": round(qa * FWD_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)}
+            "mfma_frac": round(qa * fwd_gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4)}
 
 
 def fp32_parity_mode(batch, steps=4):
@@ -168,6 +170,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--task", default="hgqa", choices=["hgqa", "vqa"],
+                    help="hgqa: BASELINE.json configs[2] (the headline: full model); vqa: configs[1] (agqaVQA.py --taskVQA 5/2/5, "
+                         "video + question path, BCE on the answer logit, no HG decoder / no Hungarian)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (the measured configuration); gloo = host "
+                         "collectives, for rehearsing the N > 1 code path of this script on a box with fewer GPUs than ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and attention-stack measurements (N=1)")
     ap.add_argument("--overlap-update", action="store_true", help="overlap BertAdam's sweep with the next step's conv1")
@@ -190,6 +198,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev:                                  # more ranks than GPUs: only meaningful for the gloo rehearsal
+        assert a.backend == "gloo", "one rank per GPU: %d ranks but %d GPUs" % (world, n_dev)
+        local = local % n_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -198,19 +210,25 @@ def main():
     from shg_vqa_amd import ddp
     from shg_vqa_amd.ddp import GradReducer
     from shg_vqa_amd.engine import engine, reset_engine
-    from shg_vqa_amd.param import hgqa_args
+    from shg_vqa_amd.param import hgqa_args, parse_args
 
     cdt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     reset_engine(compute_dtype=cdt, device=dev, seed=9595 + rank)
     if world > 1 or a.force_ddp:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        ddp.init_process_group(dev)            # the engine's streams take their hardware queues before RCCL creates its own
+        ddp.init_process_group(dev, backend=a.backend)   # the engine's streams take their hardware queues before RCCL creates its own
 
     log("imports done; building model")
-    args = hgqa_args(compute_dtype=a.dtype, batch_size=a.batch, lr=1e-5)
     torch.manual_seed(9595)                                   # identical --fromScratch initialisation on every rank
-    model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=args)
+    if a.task == "vqa":
+        args = parse_args(["--noCaps", "--crossAttnType", "cross", "--taskVQA", "--fromScratch", "--computeDtype", a.dtype,
+                           "--batchSize", str(a.batch), "--lr", "1e-5"])
+        model = AGQAModel(171, args=args)
+    else:
+        args = hgqa_args(compute_dtype=a.dtype, batch_size=a.batch, lr=1e-5)
+        model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=args)
+    train_gflop = TRAIN_GFLOP_PER_QA_VQA if a.task == "vqa" else TRAIN_GFLOP_PER_QA
     model.to_engine(cdt)
     E = engine()
     # --force-ddp with one rank: the collectives run anyway (a 1-rank all-reduce is the identity)
@@ -244,6 +262,7 @@ def main():
         log("warm-up step %d done" % i)
     sync()
     E.kernel_events = []
+    E.kernel_events_wgrad = []
     t0 = time.perf_counter()
     for i in range(a.steps):
         step_fn(batches[i % len(batches)])
@@ -262,11 +281,14 @@ def main():
 
     # dominant kernel: conv1 implicit GEMM, events recorded around its launch on its own stream
     evs = E.kernel_events or []
-    E.kernel_events = None
+    evs_w = E.kernel_events_wgrad or []
+    E.kernel_events = E.kernel_events_wgrad = None
     k_ms = sum(s.elapsed_time(e) for s, e in evs) / max(len(evs), 1)
+    kw_ms = sum(s.elapsed_time(e) for s, e in evs_w) / max(len(evs_w), 1)
     B = a.batch
-    conv1_flop = 2.0 * (B * 12 * 49) * 768 * (45 * 2048)
+    conv1_flop = 2.0 * (B * 12 * 49) * 768 * (45 * 2048)      # forward and weight gradient contract the same three extents
     achieved = conv1_flop / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    achieved_w = conv1_flop / (kw_ms * 1e-3) / 1e12 if kw_ms > 0 else 0.0
 
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_conv1_latest.json")
@@ -281,26 +303,39 @@ def main():
             "metric": "training QA-pairs/sec (node) for 5/2/5-layer SHG-VQA", "value": round(qa, 2), "unit": "QA-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "agqaHGQA.py --taskHGQA --LossHGPerFrame full SHG-VQA model, llayers/xlayers/rlayers 5/2/5, "
-                                   "dlayers 5, slow_r50-shaped feats (B,2048,16,7,7), per-GPU batch %d, random --fromScratch init "
-                                   "(BASELINE.json configs[2]; configs[4] at 8 GPUs)" % B,
+            "config": {"workload": ("agqaVQA.py --taskVQA 5/2/5 layers (video + question path, no HG decoder / no Hungarian), "
+                                    "slow_r50-shaped feats (B,2048,16,7,7), per-GPU batch %d, random --fromScratch init "
+                                    "(BASELINE.json configs[1])" % B) if a.task == "vqa" else
+                                   ("agqaHGQA.py --taskHGQA --LossHGPerFrame full SHG-VQA model, llayers/xlayers/rlayers 5/2/5, "
+                                    "dlayers 5, slow_r50-shaped feats (B,2048,16,7,7), per-GPU batch %d, random --fromScratch init "
+                                    "(BASELINE.json configs[2]; configs[4] at 8 GPUs)" % B),
+                       "backend": (a.backend if dist.is_initialized() else None),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "execution": mode, "ranks_seen": ranks_seen,
                        "grad_wire": a.grad_wire if reducer is not None else None},
-            "step_mfma_frac": round(qa / world * TRAIN_GFLOP_PER_QA * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"kernel": "gemm8_sk_kernel<bf16, ConvRowSrc, PlainSrc> (stream-K; shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
-                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_live": False,
-                         "launch_ms": round(k_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs)},
+            "step_mfma_frac": round(qa / world * train_gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
         }
+        # the two longest kernels of the step, both conv1 (2048 -> 768): its forward (stream-K implicit GEMM) and its weight
+        # gradient (main launch + split remainder launch, timed as one); `roofline` is whichever is LONGER, `roofline_rows` both
+        row_f = {"kernel": "gemm8_sk_kernel<bf16, ConvRowSrc, PlainSrc> (stream-K; shg_conv3d_k533_fwd, 2048->768)", "bound": "mfma",
+                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_live": False,
+                 "launch_ms": round(k_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs)}
+        row_w = {"kernel": "gemm8_kernel<float, PlainSrc<kstrided>, ConvColSrc> x 2 launches (whole rounds + split remainder; "
+                           "shg_conv3d_k533_wgrad, 2048->768)", "bound": "mfma",
+                 "achieved": round(achieved_w, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(achieved_w / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                 "launch_ms": round(kw_ms, 4), "flop_per_launch": conv1_flop, "launches_timed": len(evs_w)}
+        line["roofline"] = row_w if kw_ms > k_ms else row_f
+        line["roofline_rows"] = [row_f, row_w]
         if world == 1 and mode == "eager" and a.dtype == "bf16" and not a.no_extras:
             log("forward-only pass and attention-stack sub-roofline ...")
-            line["forward_only"] = forward_only(trainer, batches)
+            line["forward_only"] = forward_only(trainer, batches, fwd_gflop=FWD_GFLOP_PER_QA_VQA if a.task == "vqa" else FWD_GFLOP_PER_QA)
             line["attention_stack"] = attention_stack(trainer, B)
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle) ...")
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(task=a.task)
             log("cpu baseline done")
-        fp32_wanted = world == 1 and mode == "eager" and a.dtype == "bf16" and not a.no_extras
+        fp32_wanted = world == 1 and mode == "eager" and a.dtype == "bf16" and not a.no_extras and a.task == "hgqa"
     else:
         fp32_wanted, line = False, None
     if fp32_wanted:

@@ -8,7 +8,7 @@
  * Conventions
  *   - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer owned by the caller
  *     unless the comment says "host".  The library never allocates or frees device memory and holds
- *     no mutable global state besides the last error string, a launch counter for tests and the per-device "shared-memory limit
+ *     no mutable global state besides the last error string, the tuning table, a launch counter for tests and the per-device "shared-memory limit
  *     raised" bits of its kernels; workspaces and the executor's event ring are caller-owned handles.
  *   - Every function only enqueues work on `stream` (a hipStream_t passed as void*); it is safe to
  *     call during hipGraph stream capture.
@@ -45,6 +45,17 @@ extern "C" {
 
 int shg_version(void);
 const char* shg_last_error_string(void);
+/* Tuning switches.  The library reads NO environment variables; every dispatch threshold / kernel variant choice is one entry of a
+ * table with its measured-best default (csrc/common.h `enum Tune`, csrc/api.hip): "attn_nb", "attn_nb_dq", "attn_nb_dkv",
+ * "tile_order", "gemm4_max_tiles", "streamk_sigma", "streamk", "gemm8", "gemm8_min_tiles", "splitk_target", "splitk_min_steps",
+ * "large_min_k", "wgrad_group", "conv_wgrad_remainder", "bertadam_mode", "bertadam_blocks", "gemm8_tile_m", "attn_bwd_fused".
+ * A binding sets them once (the Python host maps SHG_<NAME> environment variables onto them at load time); host-side only, takes
+ * effect at the next launch.  shg_set_tuning: 0 or SHG_ERR_INVALID (unknown name); shg_get_tuning: value or INT64_MIN;
+ * shg_tuning_name(i): name of entry i, NULL past the end.  (The reference has no counterpart: its knobs are argparse flags,
+ * param.py:20-160.) */
+int shg_set_tuning(const char* name, int64_t value);
+int64_t shg_get_tuning(const char* name);
+const char* shg_tuning_name(int index);
 /* Diagnostics: number of convolution launches so far that used the stream-K work split of the 256 x 256 kernel (gemm.hip:
  * every CU gets the same number of K-tiles).  Tests use it to prove the path was exercised. */
 int64_t shg_gemm_streamk_launches(void);

@@ -146,6 +146,9 @@ def gen_hgqa(star=False):
 
 
 def gen_q():
+    """--taskQ (tasks/agqaQ.py:186-300): question-only model; forward logits + BCE * n_answers, the gradient of every parameter
+    that trains (norm + first values), the clipped global norm and TWO BertAdam steps as the loop runs them (the first has
+    learning rate 0 under the linear warm-up, optimization.py:142-173), with the first values of every updated tensor."""
     from . import ref_harness, shg_ref
     argv = ["ref", "--llayers", "2", "--noCaps", "--batchSize", "4", "--taskQ", "--fromScratch",
             "--optim", "bert", "--lr", "1e-5"]
@@ -156,14 +159,40 @@ def gen_q():
     model.eval()
     _load_det_weights(torch, model)
     batch = shg_ref.synthetic_batch(4, cfg, seed=77, with_feat=False)
-    logit, _ = model(None, None, input_ids=batch["input_ids"], input_masks=batch["input_mask"],
-                     segment_ids=batch["segment_ids"], rel_segment_ids=None, rel_tgt_mask=None,
-                     act_segment_ids=None, act_tgt_mask=None, hg_mask=None)
-    loss = torch.nn.BCEWithLogitsLoss()(logit, batch["target"]) * logit.size(1)
+
+    def fwd():
+        logit, _ = model(None, None, input_ids=batch["input_ids"], input_masks=batch["input_mask"],
+                         segment_ids=batch["segment_ids"], rel_segment_ids=None, rel_tgt_mask=None,
+                         act_segment_ids=None, act_tgt_mask=None, hg_mask=None)
+        return logit, torch.nn.BCEWithLogitsLoss()(logit, batch["target"]) * logit.size(1)
+
+    logit, loss = fwd()
+    lr, t_total = 1e-3, 10
+    opt = R.optimization.BertAdam(list(model.parameters()), lr=lr, warmup=0.1, t_total=t_total)
+    opt.zero_grad()
+    loss.backward()
+    gnames, gnorms, gheads = [], [], []
+    for n, prm in model.named_parameters():
+        if prm.grad is not None:
+            gnames.append(n)
+            gnorms.append(float(prm.grad.double().norm()))
+            gheads.append(_np(prm.grad.reshape(-1)[:4]).astype(np.float32))
+    total_norm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0))
+    opt.step()                                   # step 0: lr = 0
+    opt.zero_grad()
+    _, loss1 = fwd()
+    loss1.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+    opt.step()                                   # step 1: lr = 0.9 * lr
+    named = dict(model.named_parameters())
+    after = np.stack([_np(named[n].reshape(-1)[:4]).astype(np.float32) for n in gnames])
+    _, loss2 = fwd()
     np.savez_compressed(os.path.join(GOLD, "agqa_q_b4.npz"), batch_seed=np.int64(77), batch_size=np.int64(4),
-                        logit=_np(logit), loss=_np(loss),
+                        logit=_np(logit), loss=_np(loss), grad_names=np.array(gnames), grad_norms=np.array(gnorms, np.float64),
+                        grad_heads=np.stack(gheads), grad_total_norm=np.float64(total_norm), lr=np.float64(lr),
+                        t_total=np.int64(t_total), after_heads=after, loss_after=_np(loss2),
                         param_names=np.array([n for n, _ in model.named_parameters()]))
-    print("q done", float(loss))
+    print("q done", float(loss), "grad norm", total_norm, "n grads", len(gnames), "loss after 2 steps", float(loss2))
 
 
 def gen_vqa():
@@ -342,12 +371,105 @@ def gen_bertadam():
     print("bertadam done", norms)
 
 
+def gen_matcher_frames_wide():
+    """The per-frame branch of the REAL reference matcher (lxrt/matcher.py:62-80) at the class widths the model calls it with
+    (C = 457 relation classes x 8 queries per frame, C = 158 action classes x 3): 2 560 frames per head.  The logits are NOT
+    stored (2 560 x 8 x 457 values): they are multiples of 1/64 drawn from numpy's frozen legacy generator
+    (RandomState(seed).randint), regenerated by the tests and pinned here by a CRC of their bytes."""
+    import zlib
+    from . import ref_harness
+    R = ref_harness.load()
+    torch = R.torch
+    m = R.matcher.HungarianMatcher(cost_class=1, loss_hg_per_frame=True, clip_len=16)
+    out = {}
+    for tag, (per, C, seed) in {"rel": (8, 457, 457001), "act": (3, 158, 158001)}.items():
+        B, T = 160, 16                                        # 2 560 frames
+        rs = np.random.RandomState(seed)
+        k = rs.randint(-256, 257, size=(B, T * per, C)).astype(np.int16)
+        k[B // 2:] = (k[B // 2:] // 32) * 32                  # second half: coarse logits (17 levels) -> exact cost ties
+        lens = rs.randint(0, per + 1, size=(B * T,)).astype(np.int64)
+        tgt = np.zeros((B * T, per), np.int64)
+        for f in range(B * T):
+            n = int(lens[f])
+            lab = rs.randint(1, C, size=(n,))
+            if n >= 2 and f % 3 == 0:
+                lab[1] = lab[0]                               # duplicated class: identical cost columns
+            tgt[f, :n] = lab
+        logits = torch.from_numpy(k.astype(np.float32) / 64.0)
+        targets = [{"labels": [torch.from_numpy(tgt[b * T + f, :int(lens[b * T + f])]) for f in range(T)]} for b in range(B)]
+        idx = m({"pred_logits": logits}, targets)
+        oq = -np.ones((B * T, per), np.int8)
+        ot = -np.ones((B * T, per), np.int8)
+        for f, (i, j) in enumerate(idx):
+            oq[f, :len(i)], ot[f, :len(j)] = i.numpy(), j.numpy()
+        out.update({tag + "_seed": np.int64(seed), tag + "_shape": np.array([B, T, per, C], np.int64),
+                    tag + "_crc": np.int64(zlib.crc32(k.tobytes())), tag + "_tgt": tgt.astype(np.int16),
+                    tag + "_len": lens.astype(np.int8), tag + "_q": oq, tag + "_t": ot})
+    np.savez_compressed(os.path.join(GOLD, "matcher_frames_wide.npz"), **out)
+    print("matcher_frames_wide done:", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def synthetic_annotations(n=2000, seed=31):
+    """A synthetic AGQA annotation set with every category of agqa_data.py:341-1101 populated: -> (id2datum, answerVocab)."""
+    rs = np.random.RandomState(seed)
+    vocab = {("ans%d" % i): i for i in range(40)}
+    vocab["yes"], vocab["no"] = 40, 41
+    reasoning = ["obj-rel", "rel-act", "obj-act", "superlative", "sequencing", "exists", "duration-comparison", "action-recognition"]
+    id2datum = {}
+    ids = ["q%05d" % i for i in range(n)]
+    for i, qid in enumerate(ids):
+        binary = bool(rs.randint(0, 2))
+        k = int(rs.randint(1, 4))
+        glob = [reasoning[int(j)] for j in rs.randint(0, len(reasoning), size=k)]       # repeats happen (counted per occurrence)
+        d = {"question_id": qid, "question": "synthetic %d" % i, "ans_type": "binary" if binary else "open",
+             "answer": ("yes" if rs.randint(0, 2) else "no") if binary else "ans%d" % int(rs.randint(0, 40)),
+             "global": glob, "semantic": ["object", "relation", "action"][int(rs.randint(0, 3))],
+             "structural": ["query", "compare", "choose", "logic", "verify"][int(rs.randint(0, 5))],
+             "nc_seq": int(rs.randint(0, 2)), "nc_sup": int(rs.randint(0, 2)), "nc_dur": int(rs.randint(0, 2)),
+             "nc_objrel": int(rs.randint(0, 2)), "i_obj": int(rs.randint(0, 2)), "i_act": int(rs.randint(0, 2)),
+             "i_temp": int(rs.randint(0, 2)), "indirect": int(rs.randint(0, 2)), "direct_equiv": None}
+        if d["indirect"] and i > 0 and rs.randint(0, 4) != 0:
+            d["direct_equiv"] = ids[int(rs.randint(0, i))]
+        elif d["indirect"] and rs.randint(0, 2):
+            d["direct_equiv"] = "absent%05d" % i              # an equivalent that is not part of the split
+        id2datum[qid] = d
+    return id2datum, vocab
+
+
+def gen_evaluator():
+    """All result lists of the REAL AGQAEvaluator (tasks/agqa_data.py:341-1101) on a 2 000-question synthetic annotation set with
+    every category populated and predictions that are right about half of the time."""
+    from . import ref_harness
+    ref_harness.load()
+    import src.tasks.agqa_data as ad
+    id2datum, vocab = synthetic_annotations()
+    ds = types.SimpleNamespace(id2datum=id2datum, answerVocab=vocab)
+    ev = ad.AGQAEvaluator(ds)
+    rs = np.random.RandomState(7)
+    q2a = {}
+    for qid, d in id2datum.items():
+        right = rs.randint(0, 2)
+        q2a[qid] = int(vocab[d["answer"]]) if right else int(rs.randint(0, len(vocab)))
+    res = {"overall": ev.evaluateOverall(q2a), "all_qtypes": ev.evaluateAllQtypes(q2a), "comp_steps": ev.evaluateCompSteps(q2a),
+           "novel_comp": ev.evaluateNovelComp(q2a)}
+    recall, precision_qs = ev.evaluateIndirectRef(q2a)
+    res["indirect_recall"] = recall
+    res["precision_ids"] = [q["question_id"] for q in precision_qs]
+    res["precision"] = ev.evaluatePrecision(precision_qs)
+    for d in id2datum.values():
+        d.pop("prediction", None)                             # (the reference writes its prediction into the annotation)
+    with open(os.path.join(GOLD, "evaluator_2k.json"), "w") as f:
+        json.dump({"n": len(id2datum), "annotation_seed": 31, "answer_vocab": vocab, "id2datum": id2datum,
+                   "quesid2ans": q2a, "expected": res}, f, separators=(",", ":"))
+    print("evaluator done:", {k: (len(v) if isinstance(v, list) else v) for k, v in res.items()})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for v in ("hgqa", "star", "q", "vqa", "lsap", "bertadam", "matcher_clip", "matcher_frames"):
+        for v in ("hgqa", "star", "q", "vqa", "lsap", "bertadam", "matcher_clip", "matcher_frames", "matcher_frames_wide", "evaluator"):
             subprocess.check_call([sys.executable, "-m", "oracle.gen_golden", v], env=env,
                                   cwd=os.path.dirname(HERE))
     elif what == "hgqa":
@@ -366,6 +488,10 @@ def main():
         gen_vqa()
     elif what == "matcher_frames":
         gen_matcher_frames()
+    elif what == "matcher_frames_wide":
+        gen_matcher_frames_wide()
+    elif what == "evaluator":
+        gen_evaluator()
     else:
         raise SystemExit(f"unknown variant {what}")
 

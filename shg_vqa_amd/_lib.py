@@ -19,6 +19,9 @@ P, I, L, F, U = c_void_p, c_int, c_int64, c_float, c_uint64
 _SIGNATURES = {
     "shg_version": ([], c_int),
     "shg_last_error_string": ([], c_char_p),
+    "shg_set_tuning": ([c_char_p, L], c_int),
+    "shg_get_tuning": ([c_char_p], L),
+    "shg_tuning_name": ([I], c_char_p),
     "shg_gemm_streamk_launches": ([], L),
     "shg_streamk_plan": ([I, I, I, I, P], c_int),
     "shg_hungarian_per_frame": ([P, I, I, I, I, P, P, L, P, P, P, P], c_int),
@@ -149,7 +152,49 @@ def lib():
             if handle.shg_abi_sizeof(i) != ctypes.sizeof(st):
                 raise ShgError("struct layout mismatch with libshgvqa.so for %s: rebuild (python -m shg_vqa_amd.build)" % st.__name__)
         _lib = handle
+        _apply_env_tuning(handle)
     return _lib
+
+
+def tuning_names():
+    h, out, i = lib(), [], 0
+    while True:
+        nm = h.shg_tuning_name(i)
+        if nm is None:
+            return out
+        out.append(nm.decode())
+        i += 1
+
+
+def _apply_env_tuning(handle):
+    """The library itself reads no environment: SHG_<NAME> variables (e.g. SHG_GEMM8_MIN_TILES=130) are mapped onto its tuning
+    table here, once, when the library is loaded."""
+    i = 0
+    while True:
+        nm = handle.shg_tuning_name(i)
+        if nm is None:
+            break
+        env = os.environ.get("SHG_" + nm.decode().upper())
+        if env is not None:
+            if handle.shg_set_tuning(nm, int(env)) != 0:
+                raise ShgError("cannot set tuning switch %s" % nm.decode())
+        i += 1
+
+
+def set_tuning(name, value):
+    """Sets one tuning switch of the library (include/shg_vqa.h shg_set_tuning); returns the previous value."""
+    h = lib()
+    old = h.shg_get_tuning(name.encode())
+    if h.shg_set_tuning(name.encode(), int(value)) != 0:
+        raise ShgError("unknown tuning switch %r (known: %s)" % (name, ", ".join(tuning_names())))
+    return old
+
+
+def get_tuning(name):
+    v = lib().shg_get_tuning(name.encode())
+    if v == -(1 << 63):
+        raise ShgError("unknown tuning switch %r" % name)
+    return v
 
 
 def exported_names():

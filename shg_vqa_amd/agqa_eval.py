@@ -9,6 +9,10 @@ agqaHGQA.py:886-1040).  A question's annotation (`datum`) carries the reference'
 ('binary' | 'open'), global (list of reasoning types), semantic, structural, nc_seq / nc_sup / nc_dur / nc_objrel,
 i_obj / i_act / i_temp, indirect, direct_equiv.
 
+A predicate returns how often a question counts for its row: the reasoning types of `global` are tallied per OCCURRENCE
+(the reference loops `for q in qType`, agqa_data.py:520-560, so a type listed twice counts twice), everything else 0 / 1.
+`tests/golden/evaluator_2k.json` holds every result list of the reference's own class on a 2 000-question set.
+
 One deliberate difference: a category without questions yields float('nan') here, where the reference divides by
 zero and raises (its splits always populate every category; synthetic splits need not).
 """
@@ -17,15 +21,15 @@ import math
 
 
 def _is(field, value):
-    return lambda d: d.get(field) == value
+    return lambda d: 1 if d.get(field) == value else 0
 
 
 def _both(p, q):
-    return lambda d: p(d) and q(d)
+    return lambda d: p(d) if q(d) else 0
 
 
 def _has(qtype):
-    return lambda d: qtype in (d.get("global") or ())
+    return lambda d: sum(1 for q in (d.get("global") or ()) if q == qtype)
 
 
 _BIN, _OPEN = _is("ans_type", "binary"), _is("ans_type", "open")
@@ -38,7 +42,7 @@ def _tri(p):
 
 # evaluateAllQtypes (agqa_data.py:363-700): 31 rows
 ALL_QTYPES = (
-    [("overall", lambda d: True), ("binary", _BIN), ("open", _OPEN)]
+    [("overall", lambda d: 1), ("binary", _BIN), ("open", _OPEN)]
     + list(zip(("object-relationship", "object-relationship binary", "object-relationship open"), _tri(_has("obj-rel"))))
     + [("relationship-action", _has("rel-act")), ("object-action", _has("obj-act"))]
     + list(zip(("superlative", "superlative binary", "superlative open"), _tri(_has("superlative"))))
@@ -51,7 +55,7 @@ ALL_QTYPES = (
     + list(zip(("action", "action binary", "action open"), _tri(_is("semantic", "action"))))
     + [(s, _is("structural", s)) for s in ("query", "compare", "choose", "logic", "verify")]
 )
-COMP_STEPS = [("overall", lambda d: True), ("overall binary", _BIN), ("overall open", _OPEN)]              # :702-733
+COMP_STEPS = [("overall", lambda d: 1), ("overall binary", _BIN), ("overall open", _OPEN)]              # :702-733
 NOVEL_COMP = (COMP_STEPS                                                                                     # :737-883
               + list(zip(("sequencing", "sequencing binary", "sequencing open"), _tri(_is("nc_seq", 1))))
               + list(zip(("superlative", "superlative binary", "superlative open"), _tri(_is("nc_sup", 1))))
@@ -68,9 +72,10 @@ def tally(rows, items):
     hits, cnt = [0] * len(preds), [0] * len(preds)
     for datum, correct in items:
         for i, p in enumerate(preds):
-            if p(datum):
-                cnt[i] += 1
-                hits[i] += 1 if correct else 0
+            w = p(datum)
+            if w:
+                cnt[i] += w
+                hits[i] += w if correct else 0
     return [h / c if c else math.nan for h, c in zip(hits, cnt)]
 
 

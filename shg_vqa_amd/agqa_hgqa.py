@@ -272,7 +272,12 @@ class AGQA:
         # ... with ONE branch stream: a capture that forks both branch streams ends cleanly, but its replay computes the
         # relation head from a stale decoder output (deterministically; either stream alone replays bit-for-bit like eager
         # steps, tools/graph_capture_ab.py) - so the language branch runs inline in the captured step.
-        mask, E.branch_mask = E.branch_mask, E.branch_mask & int(os.environ.get("SHG_CAPTURE_BRANCH_MASK", "2"))
+        cap_mask = int(os.environ.get("SHG_CAPTURE_BRANCH_MASK", "2"))
+        if (E.branch_mask & cap_mask & 6) == 6:
+            raise RuntimeError("AGQA.capture: SHG_CAPTURE_BRANCH_MASK=%d keeps BOTH branch streams in the captured step; such a "
+                               "graph replays a stale relation-decoder output (DESIGN.md section 7 (5)) - keep one of bits 1 / 2"
+                               % cap_mask)
+        mask, E.branch_mask = E.branch_mask, E.branch_mask & cap_mask
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -313,12 +318,13 @@ class AGQA:
     def train(self, train_tuple=None, eval_tuple=None):
         dset, loader, evaluator = train_tuple or self.train_tuple
         best = 0.0
+        rank0 = _rank() == 0        # one process per GPU: rank 0 alone prints, validates and writes checkpoints
         for epoch in range(self.args.epochs):
             quesid2ans = {}
             for i, batch in enumerate(loader):
                 b = batch_to_device(batch, self.device)
                 out = self.train_step(b, overlap_update=True)
-                if i % self.args.log_freq == 0:
+                if rank0 and i % self.args.log_freq == 0:
                     msg = "\nEpoch %d: Total loss= %0.4f \tHGQA loss= %0.4f" % (epoch, out["total"].item(), out["bce"].item())
                     if "rel_ce" in out:
                         msg += "\tRel loss= %0.4f \tAct loss= %0.4f\nRel class error= %0.4f \t Act class error= %0.4f" % (
@@ -327,14 +333,19 @@ class AGQA:
                 for qid, l in zip(batch["ques_id"].tolist(), out["hg_logit"].argmax(1).cpu().tolist()):
                     quesid2ans[qid] = l
             engine().wait_params_ready()                 # the last step's update may still run on its side stream
-            print("Epoch %d: Train %0.2f" % (epoch, evaluator.evaluateOverall(quesid2ans) * 100.0), flush=True)
+            if rank0:                                    # (under data parallelism: accuracy over rank 0's shard of the epoch)
+                print("Epoch %d: Train %0.2f" % (epoch, evaluator.evaluateOverall(quesid2ans) * 100.0), flush=True)
             self.save("CURRENT")
             if eval_tuple is not None:
-                score = self.evaluate(eval_tuple)
-                if score > best:
-                    best = score
-                    self.save("BEST")
-                print("Epoch %d: Valid %0.2f  Best %0.2f" % (epoch, score * 100.0, best * 100.0), flush=True)
+                # every rank holds the same weights after the all-reduced step: rank 0 validates, the others wait in save()'s barrier
+                if rank0:
+                    score = self.evaluate(eval_tuple)
+                    improved = score > best
+                    best = max(best, score)
+                    print("Epoch %d: Valid %0.2f  Best %0.2f" % (epoch, score * 100.0, best * 100.0), flush=True)
+                else:
+                    improved = False
+                self.save("BEST", only_if=improved)
         self.save("LAST")
 
     @torch.no_grad()
@@ -408,11 +419,17 @@ class AGQA:
                 quesid2ans[qid] = int(l)
         return evaluator.evaluate(quesid2ans)
 
-    def save(self, name):
-        os.makedirs(self.output, exist_ok=True)
+    def save(self, name, only_if=True):
+        """agqaHGQA.py:859-862.  One process per GPU: rank 0 alone writes - to a temporary file that is renamed into place, so a
+        reader or a crash never sees a torn checkpoint - and every rank leaves through a barrier (all ranks must call save)."""
         engine().wait_params_ready()
-        torch.save({k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
-                   os.path.join(self.output, "%s.pth" % name))
+        if _rank() == 0 and only_if:
+            os.makedirs(self.output, exist_ok=True)
+            path = os.path.join(self.output, "%s.pth" % name)
+            tmp = "%s.tmp.%d" % (path, os.getpid())
+            torch.save({k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()}, tmp)
+            os.replace(tmp, path)
+        _barrier()
 
     def load(self, path):
         """agqaHGQA.py:864-874: strips DataParallel's `module.` prefix, strict load, refreshes bf16 shadows."""
@@ -421,6 +438,17 @@ class AGQA:
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
         self.model.load_state_dict(sd, strict=True)
         engine().refresh_shadows()
+
+
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
 
 
 # ------------------------------------------------------------------ command line (agqaHGQA.py:877-1075)
@@ -479,11 +507,14 @@ def main(argv=None):
     if args.load is not None:
         agqa.load(args.load)
     if args.test is not None:
-        for split in ("valid", "test"):
-            if split in args.test:
-                _report_test(agqa, args, split)
+        if rank == 0:                              # inference needs no exchange: one rank reports and dumps the predictions
+            for split in ("valid", "test"):
+                if split in args.test:
+                    _report_test(agqa, args, split)
+        _barrier()
         return 0
-    print("Splits in Train data:", args.train, "| oracle score of the labels: %0.2f" % (100.0 * AGQA.oracle_score(train)), flush=True)
+    if rank == 0:
+        print("Splits in Train data:", args.train, "| oracle score of the labels: %0.2f" % (100.0 * AGQA.oracle_score(train)), flush=True)
     agqa.train(train, valid)
     return 0
 

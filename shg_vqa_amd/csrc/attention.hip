@@ -558,7 +558,7 @@ static int attn_check(const AttnParams& P, int dtype, int mask_kind, float p_dro
 // of 128 with 13 of 16 waves busy, against 7 workgroups of 64); short sequences (the 40-token questions, the 48 action
 // queries) keep one block so that more workgroups exist
 static int blocks_per_wave(int rows, int dtype) {
-    static const int nb = []() { const char* e = getenv("SHG_ATTN_NB"); return e ? atoi(e) : 2; }();
+    const int nb = (int)tuning(TUNE_ATTN_NB);
     return (nb == 2 && dtype == SHG_BF16 && rows >= 96) ? 2 : 1;
 }
 
@@ -566,10 +566,14 @@ static int blocks_per_wave(int rows, int dtype) {
 
 using namespace shg;
 
-// (more than 64 KiB of dynamic LDS - the fp32 parity instantiations - needs the per-function limit raised first)
+// (more than 64 KiB of dynamic LDS - the fp32 parity instantiations - needs the per-function limit raised first: once per
+// instantiation and device, common.h raise_lds_limit)
 #define ATTN_LAUNCH(KERN, LDS, ...)                                                                                   \
     do {                                                                                                              \
-        if ((LDS) > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)); \
+        if ((LDS) > 64 * 1024) {                                                                                      \
+            static std::atomic<uint64_t> raised{0};                                                                   \
+            raise_lds_limit(raised, reinterpret_cast<const void*>(KERN), (int)(LDS));                                 \
+        }                                                                                                             \
         hipLaunchKernelGGL(KERN, grid, block, LDS, st, __VA_ARGS__);                                                  \
     } while (0)
 #define ATTN_DISPATCH_D(KERNEL, T, NB, D, LDS, ...)                                                                   \
@@ -619,7 +623,7 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
     hipStream_t st = (hipStream_t)stream;
     dim3 block(256);
     {
-        static const int nb_dq = []() { const char* e = getenv("SHG_ATTN_NB_DQ"); return e ? atoi(e) : 1; }();   // measured: 141 / 197 us (1) vs 144 / 203 us (2)
+        const int nb_dq = (int)tuning(TUNE_ATTN_NB_DQ);   // measured: 141 / 197 us (1) vs 144 / 203 us (2)
         const int nb = nb_dq == 2 ? blocks_per_wave(Sq, dtype) : 1;
         dim3 grid((Sq + 64 * nb - 1) / (64 * nb), H, B);
         if (dtype == SHG_F32)
@@ -630,7 +634,7 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
             ATTN_DISPATCH(attn_bwd_dq_kernel, bf16_t, 1, 2 * fwd_stage_bytes<bf16_t>(), P, (const bf16_t*)o, (const bf16_t*)d_o, lse, delta, (bf16_t*)dq, dq_bstride, dq_sstride);
     }
     {
-        static const int nb_dkv = []() { const char* e = getenv("SHG_ATTN_NB_DKV"); return e ? atoi(e) : 1; }();
+        const int nb_dkv = (int)tuning(TUNE_ATTN_NB_DKV);
         const int nb = nb_dkv == 2 ? blocks_per_wave(Sk, dtype) : 1;
         dim3 grid((Sk + 64 * nb - 1) / (64 * nb), H, B);
         if (dtype == SHG_F32)

@@ -24,15 +24,48 @@ void set_error(const char* msg);
 int fail_arg(const char* msg);           // records msg, returns SHG_ERR_INVALID
 int check_launch(const char* what);      // hipGetLastError -> 0 or positive hipError_t
 
+// ------------------------------------------------------------------ tuning switches
+// The library reads no environment variables: every switch is an entry of one table with its measured-best default,
+// changed through shg_set_tuning(name, value) (include/shg_vqa.h).  The host binding applies SHG_* environment variables
+// once at load time; tests flip single switches.  Launch paths read the table with one relaxed atomic load.
+enum Tune {
+    TUNE_ATTN_NB = 0,          // attention forward: 16-row blocks per wave without dropout (2) - "attn_nb"
+    TUNE_ATTN_NB_DQ,           // dQ kernel (1; measured 141 / 197 us vs 144 / 203 us with 2) - "attn_nb_dq"
+    TUNE_ATTN_NB_DKV,          // dK/dV kernel (1) - "attn_nb_dkv"
+    TUNE_TILE_ORDER,           // 0 auto, 1 N fastest, 2 M fastest - "tile_order"
+    TUNE_GEMM4_MAX_TILES,      // 128 x 128 ring kernel up to this many tiles (256) - "gemm4_max_tiles"
+    TUNE_STREAMK_SIGMA,        // stream-K head share in percent (112) - "streamk_sigma"
+    TUNE_STREAMK,              // bit 0 conv forward, 1 input gradient, 2 weight gradient (1) - "streamk"
+    TUNE_GEMM8,                // 0: no 8-phase kernel (1) - "gemm8"
+    TUNE_GEMM8_MIN_TILES,      // 8-phase kernel from this many 256 x 256 tiles (120) - "gemm8_min_tiles"
+    TUNE_SPLITK_TARGET,        // weight-gradient split-K: workgroups aimed for (384) - "splitk_target"
+    TUNE_SPLITK_MIN_STEPS,     // ... and the fewest K steps per split (8) - "splitk_min_steps"
+    TUNE_LARGE_MIN_K,          // 256 x 256 tile of the generic kernel from this K (128) - "large_min_k"
+    TUNE_WGRAD_GROUP,          // grouped weight gradients: bit 0 K % 64 == 0 groups, bit 1 ragged K (3) - "wgrad_group"
+    TUNE_CONV_WGRAD_REMAINDER, // conv weight gradient: remainder column blocks as a split launch (1) - "conv_wgrad_remainder"
+    TUNE_BERTADAM_MODE,        // (1) - "bertadam_mode"
+    TUNE_BERTADAM_BLOCKS,      // (16384) - "bertadam_blocks"
+    TUNE_GEMM8_TILE_M,         // 0 auto (rounds x fill), 256 or 192: rows of the 8-phase tile - "gemm8_tile_m"
+    TUNE_ATTN_BWD_FUSED,       // 1: one backward kernel for dQ / dK / dV where available - "attn_bwd_fused"
+    TUNE_COUNT
+};
+int64_t tuning(int key);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one bit per device in a per-instantiation mask
 // (true: the attribute has already been set for the current device)
 inline bool lds_limit_raised(std::atomic<uint64_t>& mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
-    const uint64_t bit = (uint64_t)1 << dev;
-    if (mask.load(std::memory_order_relaxed) & bit) return true;
-    mask.fetch_or(bit, std::memory_order_relaxed);
-    return false;
+    return (mask.load(std::memory_order_acquire) & ((uint64_t)1 << dev)) != 0;
+}
+// raises the limit of `func` on the current device unless `mask` says it has been done; the bit is published only AFTER
+// hipFuncSetAttribute has returned, so a second host thread either sees the bit (attribute set) or sets the attribute itself
+// (setting it twice is harmless)
+inline void raise_lds_limit(std::atomic<uint64_t>& mask, const void* func, int bytes) {
+    if (lds_limit_raised(mask)) return;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev <= 63) mask.fetch_or((uint64_t)1 << dev, std::memory_order_release);
 }
 
 // ------------------------------------------------------------------ scalar conversion

@@ -39,6 +39,7 @@ struct Exec {
     std::vector<ColsumJob> cq;
     std::vector<void*> producers;
     int64_t pending_tiles = 0;
+    int q_dtype = -1;          // storage type of the queued operands (-1: queues empty); one type per flush
 };
 
 static inline int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
@@ -93,6 +94,13 @@ static void note_producer(Exec* ex, void* stream) {
         if (p == stream) return;
     ex->producers.push_back(stream);
 }
+// a queue entry carries no type of its own: the queues hold ONE storage type between two flushes
+static int queue_dtype(Exec* ex, int dtype) {
+    if (ex->q_dtype >= 0 && ex->q_dtype != dtype)
+        return fail_arg("executor: operand dtype changed while weight gradients are queued (flush them first)");
+    ex->q_dtype = dtype;
+    return 0;
+}
 
 // (shg_colsum_accumulate takes at most 512 16-byte chunks per row: wider outputs go in column slices)
 static int colsum_sliced(const void* dy, int dtype, int64_t rows, int64_t n_out, int64_t ldy, float* gb, void* st) {
@@ -108,9 +116,14 @@ static int colsum_sliced(const void* dy, int dtype, int64_t rows, int64_t n_out,
 static int wgrad(const shg_run_t* R, const shg_linear_t& lin, const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t rows,
                  int64_t n_out, int64_t n_in, bool with_bias) {
     const bool want_b = with_bias && lin.gb;
+    // the calling stream is a producer of gradient slices even when nothing is queued here (a bias gradient written by the
+    // input-gradient GEMM's epilogue on this stream, with the weight frozen): the flush - and the data-parallel reducer
+    // behind it - must be ordered after it
+    if (R->defer_wgrad && R->wgrad_stream && R->exec) note_producer(reinterpret_cast<Exec*>(R->exec), R->stream);
     if (!lin.gw && !want_b) return 0;
     if (R->defer_wgrad && R->wgrad_stream && R->exec) {          // queued: shg_exec_flush_wgrads issues them grouped
         Exec* ex = reinterpret_cast<Exec*>(R->exec);
+        CK(queue_dtype(ex, R->dtype));
         if (lin.gw) {
             ex->wq.push_back(shg_wgrad_problem_t{dy, x, lin.gw, rows, n_out, n_in, ldy, ldx});
             ex->pending_tiles += ((n_out + 255) / 256) * ((n_in + 255) / 256);
@@ -195,8 +208,8 @@ static int finish_ln_grads(const shg_run_t* R, const shg_norm_t& ln, float* g_bi
     f.cols = cols;
     if (R->defer_wgrad && R->wgrad_stream && R->exec) {
         Exec* ex = reinterpret_cast<Exec*>(R->exec);
-        ex->fq.push_back(f);
         note_producer(ex, R->stream);
+        ex->fq.push_back(f);                         // (fp32 partial sums: no operand type involved)
         return 0;
     }
     void* st = nullptr;
@@ -485,20 +498,29 @@ extern "C" int64_t shg_exec_pending_tiles(const shg_exec_t* h) {
 extern "C" int shg_exec_flush_wgrads(shg_exec_t* h, int dtype, void* wgrad_stream) {
     Exec* ex = reinterpret_cast<Exec*>(h);
     if (!ex) return fail_arg("exec_flush_wgrads: null handle");
-    if (ex->wq.empty() && ex->cq.empty() && ex->fq.empty()) return 0;
-    if (!wgrad_stream) return fail_arg("exec_flush_wgrads: deferred weight gradients need the weight-gradient stream");
-    if (ex->events.empty()) return fail_arg("exec_flush_wgrads: shg_exec_t has no events");
+    if (ex->wq.empty() && ex->cq.empty() && ex->fq.empty()) {
+        ex->producers.clear();
+        ex->q_dtype = -1;
+        return 0;
+    }
+    // whatever happens below, the queues are emptied before this call returns: their entries point into buffers the caller
+    // only keeps alive until the flush
+    int rc = 0;
+    if (!wgrad_stream) rc = fail_arg("exec_flush_wgrads: deferred weight gradients need the weight-gradient stream");
+    else if (ex->events.empty()) rc = fail_arg("exec_flush_wgrads: shg_exec_t has no events");
+    else if (ex->q_dtype >= 0 && ex->q_dtype != dtype) rc = fail_arg("exec_flush_wgrads: dtype differs from the queued operands' type");
     // sort: problems with equal row counts next to each other (a group shares its K length best), largest first
     std::stable_sort(ex->wq.begin(), ex->wq.end(), [](const shg_wgrad_problem_t& a, const shg_wgrad_problem_t& b) { return a.rows > b.rows; });
-    for (void* p : ex->producers) {
+    for (size_t i = 0; rc == 0 && i < ex->producers.size(); ++i) {
+        void* p = ex->producers[i];
         if (p == wgrad_stream) continue;
         hipEvent_t ev = ex->events[ex->cursor];
         ex->cursor = (ex->cursor + 1) % ex->events.size();
         hipError_t e = hipEventRecord(ev, (hipStream_t)p);
         if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)wgrad_stream, ev, 0);
-        if (e != hipSuccess) { set_error(hipGetErrorString(e)); return (int)e; }
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = (int)e; }
     }
-    int rc = shg_wgrad_group(ex->wq.data(), (int)ex->wq.size(), dtype, wgrad_stream);
+    if (rc == 0) rc = shg_wgrad_group(ex->wq.data(), (int)ex->wq.size(), dtype, wgrad_stream);
     for (size_t i = 0; rc == 0 && i < ex->cq.size(); ++i) {
         const ColsumJob& c = ex->cq[i];
         rc = colsum_sliced(c.x, dtype, c.rows, c.cols, c.ld, c.out, wgrad_stream);
@@ -512,6 +534,7 @@ extern "C" int shg_exec_flush_wgrads(shg_exec_t* h, int dtype, void* wgrad_strea
     ex->cq.clear();
     ex->producers.clear();
     ex->pending_tiles = 0;
+    ex->q_dtype = -1;
     return rc;
 }
 

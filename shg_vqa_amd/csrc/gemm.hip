@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
 // tile walk inside an XCD's range: the smaller grid dimension fastest (its tiles share the other operand's panel,
 // which then comes out of the XCD's L2 instead of the Infinity Cache); encoded in the sign of grid_m
 static int tile_order(int64_t gm, int64_t gn) {
-    static const int mode = []() { const char* e = getenv("SHG_TILE_ORDER"); return e ? atoi(e) : 0; }();   // 1: N fastest, 2: M fastest
+    const int mode = (int)tuning(TUNE_TILE_ORDER);   // 1: N fastest, 2: M fastest
     const bool m_fast = mode == 2 || (mode == 0 && gm < gn);
     return m_fast ? -(int)gm : (int)gm;
 }
@@ -900,15 +900,14 @@ static int launch4(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
     const size_t lds = 4 * 4 * Tile64<bf16_t>::BYTES;
     auto kern = gemm4_kernel<TC, SrcA, SrcB>;
     static std::atomic<uint64_t> raised{0};          // per instantiation, one bit per device
-    if (!lds_limit_raised(raised))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    raise_lds_limit(raised, reinterpret_cast<const void*>(kern), (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn)), dim3(512), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn));
     return check_launch(what);
 }
 
 // small bf16 NT problems (at most `max_tiles` 128 x 128 tiles: about one workgroup per CU) with whole K-steps
 static bool use_gemm4(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t bytes_b) {
-    static const int64_t max_tiles = []() { const char* e = getenv("SHG_GEMM4_MAX_TILES"); return e ? (int64_t)atoi(e) : (int64_t)256; }();
+    const int64_t max_tiles = tuning(TUNE_GEMM4_MAX_TILES);
     if (K % BK || K < 2 * BK) return false;
     if (bytes_a >= ((int64_t)1 << 32) || bytes_b >= ((int64_t)1 << 32)) return false;
     return ((M + 127) / 128) * ((N + 127) / 128) <= max_tiles;
@@ -1345,13 +1344,11 @@ static StreamK streamk_view(void* ws) {
     return sk;
 }
 
-static bool lds_raised(std::atomic<uint64_t>& mask) { return lds_limit_raised(mask); }   // (common.h)
 
 static std::atomic<int64_t> g_streamk_launches{0};
 static int streamk_sigma() {
-    static const int v = []() { const char* e = getenv("SHG_STREAMK_SIGMA"); const int x = e ? atoi(e) : 112;   // measured: conv1 2246 / 2195 / 2190 / 2204 us, conv2 628 / 580 / 586 / 606 us at 100 / 108 / 116 / 125
-     return x < 100 ? 100 : (x > 200 ? 200 : x); }();
-    return v;
+    const int x = (int)tuning(TUNE_STREAMK_SIGMA);   // measured: conv1 2246 / 2195 / 2190 / 2204 us, conv2 628 / 580 / 586 / 606 us at 100 / 108 / 116 / 125
+    return x < 100 ? 100 : (x > 200 ? 200 : x);
 }
 
 template <typename TC, typename SrcA, typename SrcB, int ALLOW_SK = 0>     // ALLOW_SK: bit of SHG_STREAMK that enables the split
@@ -1368,7 +1365,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
         // instantiated any more:
         // bit 1 conv input gradient (measured slower: 791 -> 859 us), bit 2 conv weight gradient (2x slower: the gathered-B
         // variant of the segment loop does not keep its registers)
-        static const int streamk = []() { const char* e = getenv("SHG_STREAMK"); return e ? atoi(e) : 1; }();
+        const int streamk = (int)tuning(TUNE_STREAMK);
         // (every XCD needs 16 <= R < 32 tiles: heads and tails both exist and a tile's tail is cut at most once)
         const int64_t r_min = tiles / 8, r_max = (tiles + 7) / 8, sg = streamk_sigma();
         const int64_t per_wg = (sg * r_max * nk + 100 * (32 - r_max) + sg * r_max - 1) / (100 * (32 - r_max) + sg * r_max);   // head length
@@ -1378,8 +1375,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
             {
                 auto kern = gemm8_sk_kernel<TC, SrcA, SrcB>;
                 static std::atomic<uint64_t> raised_sk{0};   // per instantiation, one bit per device
-                if (!lds_raised(raised_sk))
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                raise_lds_limit(raised_sk, reinterpret_cast<const void*>(kern), (int)lds);
                 sk.n_tiles = (int)tiles;
                 sk.sigma = (int)sg;
                 g_streamk_launches.fetch_add(1, std::memory_order_relaxed);
@@ -1390,8 +1386,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
     }
     auto kern = gemm8_kernel<TC, SrcA, SrcB, false>;
     static std::atomic<uint64_t> raised{0};          // per instantiation, one bit per device
-    if (!lds_raised(raised))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    raise_lds_limit(raised, reinterpret_cast<const void*>(kern), (int)lds);
     if (split > 1) ep.atomic = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, split), dim3(512), lds, st, sa, sb, ep, M, N, K,
                        tile_order(gm, gn), StreamK{nullptr, nullptr, 0, 100});
@@ -1401,8 +1396,8 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
 // the 8-phase kernel is used for bf16 problems with whole K-steps, >= 2 of them, at least `min_tiles` (about half the CUs)
 // 256 x 256 tiles and operands addressable with 32-bit byte offsets
 static bool use_gemm8(int64_t M, int64_t N, int64_t K, int64_t bytes_a, int64_t bytes_b) {
-    static const int mode = []() { const char* e = getenv("SHG_GEMM8"); return e ? atoi(e) : 1; }();
-    static const int64_t min_tiles = []() { const char* e = getenv("SHG_GEMM8_MIN_TILES"); return e ? (int64_t)atoi(e) : (int64_t)120; }();   // 96 tiles (4096 x 1536): the 128 x 128 kernel wins, 21 vs 31 us
+    const int mode = (int)tuning(TUNE_GEMM8);
+    const int64_t min_tiles = tuning(TUNE_GEMM8_MIN_TILES);   // 96 tiles (4096 x 1536): the 128 x 128 kernel wins, 21 vs 31 us
     if (!mode || K % BK || K < 2 * BK) return false;
     if (bytes_a >= ((int64_t)1 << 32) || bytes_b >= ((int64_t)1 << 32)) return false;
     return ((M + 255) / 256) * ((N + 255) / 256) >= min_tiles;
@@ -1423,16 +1418,15 @@ static int launch_cfg(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, i
     int split = 1;
     const int64_t nk = (K + BK - 1) / BK;
     if (allow_split && ep.accumulate && gm * gn < 384) {
-        static const int64_t target = []() { const char* e = getenv("SHG_SPLITK_TARGET"); return e ? (int64_t)atoi(e) : (int64_t)384; }();
-        static const int64_t min_steps = []() { const char* e = getenv("SHG_SPLITK_MIN_STEPS"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
+        const int64_t target = std::max<int64_t>(1, tuning(TUNE_SPLITK_TARGET));
+        const int64_t min_steps = std::max<int64_t>(1, tuning(TUNE_SPLITK_MIN_STEPS));
         split = (int)std::min<int64_t>((target + gm * gn - 1) / (gm * gn), std::max<int64_t>(1, nk / min_steps));
         if (split > 1) ep.atomic = 1;
     }
     auto kern = gemm_kernel<T, TC, SrcA, SrcB, TM, TN, WM, WN>;
     if (lds > 64 * 1024) {
         static std::atomic<uint64_t> raised{0};      // per instantiation, one bit per device
-        if (!lds_raised(raised))
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raise_lds_limit(raised, reinterpret_cast<const void*>(kern), (int)lds);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(gm * gn), split), dim3(NTHR), lds, st, sa, sb, ep, M, N, K, tile_order(gm, gn));
     return check_launch(what);
@@ -1443,7 +1437,7 @@ constexpr int64_t LARGE_MIN_TILES = 128;
 
 static bool use_large(int dtype_is_bf16, int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    static const int64_t min_k = []() { const char* e = getenv("SHG_LARGE_MIN_K"); return e ? (int64_t)atoi(e) : (int64_t)128; }();
+    const int64_t min_k = tuning(TUNE_LARGE_MIN_K);
     return dtype_is_bf16 && tiles >= LARGE_MIN_TILES && K >= min_k;
 }
 
@@ -1572,7 +1566,7 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
     using SA = PlainSrc<bf16_t, false>;
     using Grp = G8Group<float, SA, SA>;
     // SHG_WGRAD_GROUP: bit 0 grouped launches, bit 1 also for row counts that are not a multiple of 64 (ragged last K-tile)
-    static const int mode = []() { const char* e = getenv("SHG_WGRAD_GROUP"); return e ? atoi(e) : 3; }();
+    const int mode = (int)tuning(TUNE_WGRAD_GROUP);
     int i = 0;
     while (i < n) {
         // take a run of problems the 8-phase kernel can do: bf16, whole 64-row K-tiles, 16-byte aligned rows
@@ -1616,8 +1610,7 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
             auto kern = gemm8_group_kernel<float, SA, SA>;
             const size_t lds = std::max<size_t>(2 * 8 * Tile64<bf16_t>::BYTES, (size_t)8 * 64 * STG_LD * 4);
             static std::atomic<uint64_t> raised{0};
-            if (!lds_raised(raised))
-                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raise_lds_limit(raised, reinterpret_cast<const void*>(kern), (int)lds);
             hipLaunchKernelGGL(kern, dim3((unsigned)first), dim3(512), lds, st, g);
             if (int e = check_launch("wgrad_group")) return e;
             i = j;
@@ -1784,7 +1777,7 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
         // The column blocks of the whole rounds go out as one launch; the remaining blocks as a second launch with the
         // contraction split over gridDim.y (fp32 atomic adds into the running sum - which is why this needs `accumulate`),
         // so that the remainder takes a fraction of a round.  SHG_CONV_WGRAD_REMAINDER=0 switches it off.
-        static const int rem_on = []() { const char* e = getenv("SHG_CONV_WGRAD_REMAINDER"); return e ? atoi(e) : 1; }();
+        const int rem_on = (int)tuning(TUNE_CONV_WGRAD_REMAINDER);
         const int64_t tiles_m = (cn + 255) / 256, gn = Ncols / 256, total = tiles_m * gn, rounds = total / 256, rem = total % 256;
         if (rem_on && accumulate && Ncols % 256 == 0 && rounds >= 1 && rem > 0 && Mo / BK >= 16) {
             const int64_t gn_a = rounds * 256 / tiles_m, gn_b = gn - gn_a, tiles_b = tiles_m * gn_b;

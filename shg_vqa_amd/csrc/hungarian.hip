@@ -371,10 +371,9 @@ extern "C" int shg_hungarian_per_frame(const void* logits, int dtype, int n_fram
                            2 * (size_t)per_frame + 64;
         if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("hungarian: bad dtype");
         static std::atomic<uint64_t> raised{0};      // one bit per device
-        if (!lds_limit_raised(raised)) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(hungarian_wave_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(hungarian_wave_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        }
+        static std::atomic<uint64_t> raised_b{0};
+        raise_lds_limit(raised, reinterpret_cast<const void*>(hungarian_wave_kernel<float>), 96 * 1024);
+        raise_lds_limit(raised_b, reinterpret_cast<const void*>(hungarian_wave_kernel<bf16_t>), 96 * 1024);
         if (dtype == SHG_F32)
             hipLaunchKernelGGL(hungarian_wave_kernel<float>, dim3(n_frames), dim3(64), lds, st, (const float*)logits, n_frames,
                                per_frame, n_classes, tgt, tgt_len, background_class, out_query, out_target, out_grid);

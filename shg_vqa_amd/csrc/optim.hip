@@ -153,8 +153,8 @@ extern "C" int shg_bertadam_arena(float* param, float* grad, float* m, float* v,
     if (shadow_bf16 && (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)) return fail_arg("bertadam: shadow must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (n > 0) {
-        static const int adam_mode = []() { const char* e = getenv("SHG_BERTADAM_MODE"); return e ? atoi(e) : 1; }();
-        static const int64_t adam_blocks = []() { const char* e = getenv("SHG_BERTADAM_BLOCKS"); return e ? (int64_t)atoi(e) : (int64_t)16384; }();   // measured: 2 048 .. 8 192 blocks 4.3-4.5 TB/s, 16 384 4.8
+        const int adam_mode = (int)tuning(TUNE_BERTADAM_MODE);
+        const int64_t adam_blocks = std::max<int64_t>(1, tuning(TUNE_BERTADAM_BLOCKS));   // measured: 2 048 .. 8 192 blocks 4.3-4.5 TB/s, 16 384 4.8
         const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, adam_blocks);
         hipLaunchKernelGGL(bertadam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, m, v, (bf16_t*)shadow_bf16,
                            n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state, adam_mode, (bump_step >> 1) & 1);

@@ -166,8 +166,10 @@ class Engine:
         from . import _lib
         if self.pending_keep or _lib.lib().shg_exec_pending_tiles(self._exec) > 0:
             side = self.wgrad_stream()
-            _lib.call("shg_exec_flush_wgrads", self._exec, self._run.dtype, side.cuda_stream if side is not None else None)
-            self.pending_keep.clear()
+            try:                                   # (the library empties its queues on every exit path, so may we)
+                _lib.call("shg_exec_flush_wgrads", self._exec, self._run.dtype, side.cuda_stream if side is not None else None)
+            finally:
+                self.pending_keep.clear()
             if self.grad_ready_hook is not None:
                 burst = getattr(getattr(self.grad_ready_hook, "__self__", None), "burst", None)
                 if burst is not None:

@@ -472,6 +472,23 @@ def _padded_grad_buffer(E, B, To, H, W, C, dtype, device):
     return hit
 
 
+def _event_pair(E, attr):
+    """bench.py's live kernel timing: when the engine carries a list under `attr`, an event is recorded on the current stream
+    now and another one by _event_done (both around launches on THIS stream)."""
+    evs = getattr(E, attr, None)
+    if evs is None:
+        return None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return evs, e0, e1
+
+
+def _event_done(tm):
+    if tm is not None:
+        tm[2].record()
+        tm[0].append((tm[1], tm[2]))
+
+
 class _VisualConvTokens(torch.autograd.Function):
     """Second conv + token assembly of VisualFeatEncoder (mc:991-996, :1037-1073) and the backward of
     BOTH convolutions: conv(5,3,3) 768->768 + bias + GELU -> tokens [B, 392, C] in (t,h,w) order,
@@ -547,11 +564,15 @@ class _VisualConvTokens(torch.autograd.Function):
             cout, per = w1._shg_grad.shape[0], w1._shg_grad[0].numel()
             cut = (cout // 256) * 2 // 3 * 256
             parts = [(0, cut), (cut, cout - cut)] if 0 < cut < cout else [(0, cout)]
+            tm = _event_pair(E, "kernel_events_wgrad")
             for c0, cn in parts:
                 K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True, c0=c0, cn=cn)
                 E.grad_written(w1, c0 * per, cn * per)
+            _event_done(tm)
         elif inline:
+            tm = _event_pair(E, "kernel_events_wgrad")
             K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
+            _event_done(tm)
             E.grad_written(w1)
             K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
             E.grad_written(w2)

@@ -53,3 +53,21 @@ def test_fastcall_trampoline_reaches_the_library_and_checks_arity():
     ent = _lib._FAST["shg_gemm"]
     with pytest.raises(TypeError):
         _lib._fast.call(ent[0], ent[1], 1, 2, 3)
+
+
+def test_library_reads_no_environment_and_exposes_its_tuning_table():
+    """Every switch sits behind shg_set_tuning (host-only calls: no GPU needed); the kernels' sources hold no getenv."""
+    import pytest
+    from shg_vqa_amd import _lib
+    csrc = os.path.join(ROOT, "shg_vqa_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    names = _lib.tuning_names()
+    assert len(names) >= 16 and "gemm8_min_tiles" in names and "attn_nb_dq" in names
+    assert _lib.get_tuning("gemm8_min_tiles") == 120
+    old = _lib.set_tuning("gemm8_min_tiles", 130)
+    assert old == 120 and _lib.get_tuning("gemm8_min_tiles") == 130
+    _lib.set_tuning("gemm8_min_tiles", old)
+    with pytest.raises(_lib.ShgError, match="unknown tuning switch"):
+        _lib.set_tuning("no_such_switch", 1)

@@ -191,3 +191,29 @@ def test_grad_reducer_through_rccl_single_rank_equals_the_plain_step():
     res = q.get(timeout=900)
     p.join(timeout=120)
     assert res.startswith("ok"), res
+
+
+def test_bench_world_2_branch_runs_under_torch_distributed_run_on_one_gpu():
+    """The N > 1 branch of bench.py (rendezvous from the environment, per-rank seeds, the gradient reducer, barrier + MAX-over-ranks
+    timing, the all-gather of rank ids, ONE JSON line from rank 0) launched exactly as the driver launches it - two ranks of
+    `python -m torch.distributed.run ... bench.py --gpus 2` - but with `--backend gloo` so that both ranks can share this
+    box's single GPU (RCCL needs one device per rank)."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--backend", "gloo", "--no-cpu-baseline", "--no-extras"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["backend"] == "gloo"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2 * 1e-3)) < 0.02 * d["value"]
+    assert d["roofline"]["launches_timed"] == 2 and len(d["roofline_rows"]) == 2

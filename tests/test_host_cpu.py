@@ -335,3 +335,28 @@ def test_precompute_features_fills_the_cache_the_loader_reads(tmp_path):
     assert P.main(["--backbone", "tests.test_host_cpu:tiny_backbone", "--clips", str(clips), "--out", str(tmp_path / "c3"),
                    "--batch", "3", "--device", "cpu"]) == 0
     assert torch.equal(FeatureCache(str(tmp_path / "c3"))[4], cache[4])
+
+
+def test_agqa_evaluator_reproduces_the_reference_evaluator_on_2000_questions(golden_dir):
+    """tests/golden/evaluator_2k.json (oracle/gen_golden.py evaluator): every result list of the REAL AGQAEvaluator
+    (agqa_data.py:350-362, :364-700, :702-733, :737-883, :886-976, :978-1101) on a synthetic annotation set with all categories
+    populated and repeated reasoning types - reproduced value for value, by position."""
+    import json
+    import types
+    from shg_vqa_amd.agqa_eval import ALL_QTYPES, COMP_STEPS, INDIRECT, NOVEL_COMP, AGQAEvaluator
+    g = json.load(open(os.path.join(golden_dir, "evaluator_2k.json")))
+    assert g["n"] == 2000 and len(g["quesid2ans"]) == 2000
+    assert any(len(set(d["global"])) < len(d["global"]) for d in g["id2datum"].values())      # per-occurrence counting is exercised
+    ev = AGQAEvaluator(types.SimpleNamespace(id2datum=g["id2datum"], answerVocab=g["answer_vocab"]))
+    q2a, exp = g["quesid2ans"], g["expected"]
+    assert (len(ALL_QTYPES), len(COMP_STEPS), len(NOVEL_COMP), len(INDIRECT)) == (31, 3, 15, 9)
+    assert ev.evaluateOverall(q2a) == exp["overall"]
+    for got, key in ((ev.evaluateAllQtypes(q2a), "all_qtypes"), (ev.evaluateCompSteps(q2a), "comp_steps"),
+                     (ev.evaluateNovelComp(q2a), "novel_comp")):
+        assert len(got) == len(exp[key]), key
+        assert all(abs(a - b) < 1e-12 for a, b in zip(got, exp[key])), (key, got, exp[key])
+    recall, pq = ev.evaluateIndirectRef(q2a)
+    assert all(abs(a - b) < 1e-12 for a, b in zip(recall, exp["indirect_recall"]))
+    assert [q["question_id"] for q in pq] == exp["precision_ids"]
+    prec = ev.evaluatePrecision(pq)
+    assert all(abs(a - b) < 1e-12 for a, b in zip(prec, exp["precision"]))

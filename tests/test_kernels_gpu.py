@@ -841,6 +841,25 @@ def test_hungarian_per_frame_bit_exact_vs_reference_matcher_golden_10k_frames(K,
     assert torch.equal(grid.cpu(), exp)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tag", ["rel", "act"])
+def test_hungarian_per_frame_bit_exact_vs_reference_matcher_golden_at_model_class_widths(K, golden_dir, tag, dtype):
+    """matcher.py:62-80 at the widths the model calls it with (8 x 457 and 3 x 158 per frame: the register-resident <= 512-class
+    path of the kernel): 2 560 frames per head, indices from the REAL reference matcher (oracle/gen_golden.py
+    matcher_frames_wide; the logits - multiples of 1/64, exact in bf16 - are regenerated from the stored seed and CRC-checked)."""
+    from test_oracle_golden import _wide_frames
+    g = np.load(os.path.join(golden_dir, "matcher_frames_wide.npz"))
+    k, B, T, per, C = _wide_frames(g, tag)
+    n = B * T
+    logits = (torch.from_numpy(k.astype(np.float32)) / 64.0).to(dtype).view(n, per, C)
+    tgt = torch.from_numpy(g[tag + "_tgt"].astype(np.int64)).to(DEV)
+    lens = torch.from_numpy(g[tag + "_len"].astype(np.int32)).to(DEV)
+    oq, ot, grid = K.hungarian_per_frame(logits.to(DEV).contiguous(), tgt, lens)
+    gq, gt = g[tag + "_q"].astype(np.int64), g[tag + "_t"].astype(np.int64)
+    bad = np.nonzero((oq.cpu().numpy() != gq).any(1) | (ot.cpu().numpy() != gt).any(1))[0]
+    assert bad.size == 0, (tag, dtype, bad[:10], oq[bad[:1]].cpu(), gq[bad[:1]])
+
+
 # ------------------------------------------------------------------------------------------ convolutions at the benchmark's shape
 def _im2col(xp, T_out, H, W):
     """Rows of the implicit GEMM: windows (5,3,3) of a zero-bordered channels-last tensor [B, T, H+2, W+2, C] -> [B*T_out*H*W, 45*C]."""

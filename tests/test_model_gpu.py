@@ -214,7 +214,7 @@ def test_state_dict_roundtrip_keeps_reference_keys(tmp_path, golden_dir):
     assert a.data_ptr() == c.data_ptr()
 
 
-def _build_task(task_flag, extra=(), n_ans=171):
+def _build_task(task_flag, extra=(), n_ans=171, t_total=100):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from shg_vqa_amd.agqa_hgqa import AGQA, SyntheticAGQA, DataTuple
@@ -226,7 +226,7 @@ def _build_task(task_flag, extra=(), n_ans=171):
     model = AGQAModel(n_ans, args=args)
     model.to_engine(torch.float32)
     _load_det_weights(model)
-    return AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=4), [None] * 10, None), model=model, t_total=100)
+    return AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=4), [None] * 10, None), model=model, t_total=t_total)
 
 
 def test_question_only_model_matches_reference_golden(golden_dir):
@@ -244,6 +244,50 @@ def test_question_only_model_matches_reference_golden(golden_dir):
     assert _rel_err(out["logit"], g["logit"]) < 1e-3
     assert abs(float(out["total"]) - float(g["loss"])) < 1e-3 * float(g["loss"])
     assert set(n for n, _ in tr.model.named_parameters()) == set(str(x) for x in g["param_names"])
+
+
+def test_question_only_backward_and_two_optimiser_steps_match_reference_golden(golden_dir):
+    """BASELINE.json configs[0] through the loop of agqaQ.py:186-300 on the REAL reference (oracle/gen_golden.py q): the gradient
+    of each of the 43 tensors that train, the clipped global norm, and two BertAdam steps (the first at learning rate 0 under the
+    warm-up): first values of every updated tensor and the loss afterwards."""
+    from oracle import shg_ref
+    g = np.load(os.path.join(golden_dir, "agqa_q_b4.npz"))
+    tr = _build_task("--taskQ", ["--llayers", "2", "--lr", repr(float(g["lr"]))], t_total=int(g["t_total"]))
+    cfg = shg_ref.Cfg(llayers=2, task="q")
+    batch = shg_ref.synthetic_batch(int(g["batch_size"]), cfg, seed=int(g["batch_seed"]), with_feat=False)
+    b = {k: v.to(DEV) for k, v in batch.items() if torch.is_tensor(v)}
+    from shg_vqa_amd.engine import engine
+    from shg_vqa_amd.optimization import clip_grad_norm_
+    E = engine()
+    tr.model.eval()
+    names = [str(x) for x in g["grad_names"]]
+    params = dict(tr.model.named_parameters())
+    assert set(names) == tr.model.active_parameter_names()
+    for step in range(2):
+        E.begin_step()
+        tr.optim.zero_grad()
+        E.training = False
+        out = tr.forward_losses(b)
+        out["total"].backward()
+        E.join_side_streams()
+        if step == 0:
+            for i, n in enumerate(names):
+                ref = g["grad_norms"][i]
+                got = params[n].grad.double().norm().item()
+                assert abs(got - ref) <= 5e-3 * ref + 1e-6, (n, got, ref)
+                head = params[n].grad.reshape(-1)[:4].float().cpu().numpy()
+                assert np.allclose(head, g["grad_heads"][i], rtol=5e-3, atol=5e-3 * ref / max(params[n].numel(), 1) ** 0.5 + 1e-7), (n, head)
+        tot = clip_grad_norm_(tr.model.parameters(), 5.0).item()
+        if step == 0:
+            assert abs(tot - float(g["grad_total_norm"])) <= 2e-3 * float(g["grad_total_norm"])
+        tr.optim.step()
+    torch.cuda.synchronize()
+    for i, n in enumerate(names):
+        head = params[n].detach().reshape(-1)[:4].float().cpu().numpy()
+        assert np.allclose(head, g["after_heads"][i], rtol=1e-3, atol=2e-5), (n, head, g["after_heads"][i])
+    E.begin_step()
+    out = tr.forward_losses(b)
+    assert abs(float(out["total"]) - float(g["loss_after"])) < 2e-3 * float(g["loss_after"])
 
 
 def test_vqa_task_matches_reference_golden(golden_dir):

@@ -107,6 +107,59 @@ def test_q_only_matches_reference(golden_dir):
     _close(loss, g["loss"], 1e-5, 1e-5)
 
 
+def test_q_only_backward_and_two_optimiser_steps_match_reference(golden_dir):
+    """agqaQ.py:186-300 through the REAL reference (golden) vs the oracle's train_step: every gradient, the clipped norm, two
+    BertAdam steps (first values of every updated tensor) and the loss afterwards."""
+    g = np.load(os.path.join(golden_dir, "agqa_q_b4.npz"))
+    cfg = shg_ref.Cfg(llayers=2, task="q")
+    p = shg_ref.det_params(cfg, requires_grad=True)
+    batch = shg_ref.synthetic_batch(int(g["batch_size"]), cfg, seed=int(g["batch_seed"]), with_feat=False)
+    names = [str(x) for x in g["grad_names"]]
+    state = {}
+    for step in range(2):
+        out, losses, grads, norm = shg_ref.train_step(p, cfg, batch, state, lr=float(g["lr"]), step=step, t_total=int(g["t_total"]))
+        if step == 0:
+            assert set(grads) == set(names)
+            assert abs(float(norm) - float(g["grad_total_norm"])) <= 1e-3 * float(g["grad_total_norm"])
+            coef = min(5.0 / (float(norm) + 1e-6), 1.0)               # train_step returns the CLIPPED gradients
+            for i, k in enumerate(names):
+                n_ref, n_got = g["grad_norms"][i], float(grads[k].double().norm()) / coef
+                assert abs(n_got - n_ref) <= 2e-3 * max(n_ref, 1e-6) + 1e-7, (k, n_got, n_ref)
+    for i, k in enumerate(names):
+        _close(p[k].detach().reshape(-1)[:4], g["after_heads"][i], 2e-4, 2e-6)
+    out = shg_ref.agqa_forward(p, cfg, batch)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out["logit"], batch["target"]) * cfg.num_answers
+    _close(loss.detach(), g["loss_after"], 1e-3, 1e-3)
+
+
+def _wide_frames(g, tag):
+    """matcher_frames_wide.npz keeps the generator seed instead of the logits (oracle/gen_golden.py matcher_frames_wide)."""
+    import zlib
+    B, T, per, C = (int(x) for x in g[tag + "_shape"])
+    rs = np.random.RandomState(int(g[tag + "_seed"]))
+    k = rs.randint(-256, 257, size=(B, T * per, C)).astype(np.int16)
+    k[B // 2:] = (k[B // 2:] // 32) * 32
+    assert zlib.crc32(k.tobytes()) == int(g[tag + "_crc"]), "numpy's legacy generator no longer reproduces the golden logits"
+    return k, B, T, per, C
+
+
+def test_oracle_per_frame_matching_equals_reference_matcher_at_model_class_widths(golden_dir):
+    """matcher.py:62-80 as the model calls it (8 queries x 457 relation classes, 3 x 158 action classes per frame): the REAL
+    reference matcher's indices on 2 560 frames per head (golden) vs the oracle, bit-exact."""
+    g = np.load(os.path.join(golden_dir, "matcher_frames_wide.npz"))
+    for tag in ("rel", "act"):
+        k, B, T, per, C = _wide_frames(g, tag)
+        n = B * T
+        assert n >= 2048
+        logits = torch.from_numpy(k.astype(np.float32) / 64.0)
+        lens = g[tag + "_len"].astype(np.int64)
+        labels = [torch.from_numpy(g[tag + "_tgt"][f, :lens[f]].astype(np.int64)) for f in range(n)]
+        idx = shg_ref.hungarian_per_frame(logits, labels, clip_len=16)
+        for f, (qi, ti) in enumerate(idx):
+            m = int(lens[f])
+            assert np.array_equal(qi.numpy(), g[tag + "_q"][f, :m]) and np.array_equal(ti.numpy(), g[tag + "_t"][f, :m]), (tag, f)
+
+
 def test_bertadam_and_clip_match_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "bertadam_steps.npz"))
     params = {str(i): torch.from_numpy(g[f"init{i}"].copy()) for i in range(3)}
