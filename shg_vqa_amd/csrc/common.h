@@ -43,10 +43,13 @@ enum Tune {
     TUNE_LARGE_MIN_K,          // 256 x 256 tile of the generic kernel from this K (128) - "large_min_k"
     TUNE_WGRAD_GROUP,          // grouped weight gradients: bit 0 K % 64 == 0 groups, bit 1 ragged K (3) - "wgrad_group"
     TUNE_CONV_WGRAD_REMAINDER, // conv weight gradient: remainder column blocks as a split launch (1) - "conv_wgrad_remainder"
-    TUNE_BERTADAM_MODE,        // (1) - "bertadam_mode"
-    TUNE_BERTADAM_BLOCKS,      // (16384) - "bertadam_blocks"
+    TUNE_BERTADAM_MODE,        // bit 0: two vectors per lane, 3: four, 1: non-temporal stores of shadow / zeroed gradient too,
+                               // 2: no non-temporal accesses (3; isolated at 289 M parameters: 1.575 ms = 6.24 TB/s against
+                               // 1.677 ms for the round-2 setting 1 / 16 384 blocks, tools/bertadam_bench.py) - "bertadam_mode"
+    TUNE_BERTADAM_BLOCKS,      // grid cap (65536) - "bertadam_blocks"
     TUNE_GEMM8_TILE_M,         // 0 auto (rounds x fill), 256 or 192: rows of the 8-phase tile - "gemm8_tile_m"
     TUNE_ATTN_BWD_FUSED,       // 1: one backward kernel for dQ / dK / dV where available - "attn_bwd_fused"
+    TUNE_EPILOGUE_SIDE,        // 1: GEMM row writers issue the loads of `C +=` / activation-backward forms up front - "epilogue_side"
     TUNE_COUNT
 };
 int64_t tuning(int key);

@@ -287,6 +287,7 @@ template <typename TC> struct Epilogue {
     float drop_scale;
     const uint64_t* seed_state;
     uint64_t stream_id;
+    int no_side;              // 1: the row writers' up-front-load forms are switched off ("epilogue_side" tuning switch, A/B runs)
 };
 
 __device__ __forceinline__ float act_grad_rt(float u, int act, bool fast) {
@@ -323,14 +324,17 @@ template <typename TC> struct RowWriter;
 template <> struct RowWriter<bf16_t> {
     // csum_carry (8 floats per lane, zero-initialised by the caller): the column sums of this piece are added to it instead
     // of going to memory; the caller flushes them once with flush_csum (fewer atomics on the shared bias-gradient vector)
-    __device__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
+    // SIDE: compile the whole-tile forms that read a second operand (accumulate / activation backward) with their loads up front
+    // (off in the stream-K convolution kernel, which has no register to spare and never uses them)
+    template <bool SIDE = true>
+    __device__ __forceinline__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0, float* csum_carry = nullptr) {
-        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
-        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
-        else run_act<SHG_ACT_NONE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU, SIDE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU, SIDE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        else run_act<SHG_ACT_NONE, SIDE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
     }
-    template <int ACT>
-    __device__ static void run_act(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
+    template <int ACT, bool SIDE>
+    __device__ __forceinline__ static void run_act(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                    int64_t N, int lane, int gap, float* csum_carry) {
         float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const bool drop = ep.drop_thr != 0;
@@ -372,6 +376,62 @@ template <> struct RowWriter<bf16_t> {
                     o[4 + r] = (bf16_t)act_ct<ACT, true>(vb[p][r] + bias8[4 + r]);
                 }
                 *reinterpret_cast<bf16x8*>(dst0 + (int64_t)(8 * p) * ep.ldc) = o;
+            }
+            return;
+        }
+        // the two input-gradient forms of the BERT blocks on whole tiles: `C += A.B` (the residual gradient is already in C) and
+        // `C = (A.B) * act'(gpre)` with the bias-gradient column sums.  Their global READS (old C / the saved pre-activation) are
+        // all issued before the first row pass - in the general loop below each pass waits for its own load, eight dependent L2
+        // round trips per call - with constant indices only, so that the eight vectors stay in registers (32 VGPRs)
+        if (SIDE && !ep.no_side && (ep.accumulate || ep.gpre) && !(ep.accumulate && ep.gpre) && !drop && !ep.pre && !ep.crow && ep.vec_ok && nv == 8 && mbase + 64 <= M) {
+            bf16_t* dst0 = ep.c + (mbase + (lane >> 3)) * ep.ldc + n;
+            const bf16_t* src0 = ep.gpre ? ep.gpre + (mbase + (lane >> 3)) * N + n : dst0;
+            const int64_t lds_ = ep.gpre ? N : ep.ldc;
+            const bool dact = ep.gpre != nullptr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {            // four row passes at a time: 16 VGPRs of loaded vectors in flight
+                bf16x8 s0 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h) * lds_);
+                bf16x8 s1 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h + 8) * lds_);
+                bf16x8 s2 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h + 16) * lds_);
+                bf16x8 s3 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h + 24) * lds_);
+                auto pass = [&](int p, const bf16x8& side) {
+                    const int row = 8 * p + (lane >> 3);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col + 4);
+                    const float u[8] = {a[0] + bias8[0], a[1] + bias8[1], a[2] + bias8[2], a[3] + bias8[3],
+                                        b[0] + bias8[4], b[1] + bias8[5], b[2] + bias8[6], b[3] + bias8[7]};
+                    bf16x8 o;
+                    if (dact) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            o[r] = (bf16_t)(u[r] * act_grad_ct<ACT, true>((float)side[r]));
+                            csum8[r] += (float)o[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(act_ct<ACT, true>(u[r]) + (float)side[r]);
+                    }
+                    *reinterpret_cast<bf16x8*>(dst0 + (int64_t)(8 * p) * ep.ldc) = o;
+                };
+                // (scheduling fences: left alone, the scheduler gathers the LDS reads of all passes at the top - 64 more live
+                //  registers beside the second half's accumulators - and the kernel spills 528 bytes per lane)
+                __builtin_amdgcn_sched_barrier(0);
+                pass(4 * h, s0);
+                __builtin_amdgcn_sched_barrier(0);
+                pass(4 * h + 1, s1);
+                __builtin_amdgcn_sched_barrier(0);
+                pass(4 * h + 2, s2);
+                __builtin_amdgcn_sched_barrier(0);
+                pass(4 * h + 3, s3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ep.csum) {
+                if (csum_carry) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) csum_carry[r] += csum8[r];
+                } else {
+                    flush_csum(csum8, ep, nbase, N, lane, gap);
+                }
             }
             return;
         }
@@ -460,14 +520,15 @@ template <> struct RowWriter<bf16_t> {
 };
 template <> struct RowWriter<float> {
     __device__ static void flush_csum(float*, const Epilogue<float>&, int64_t, int64_t, int, int = 0) {}
-    __device__ static void run(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
+    template <bool SIDE = true>
+    __device__ __forceinline__ static void run(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0, float* /*csum_carry: fp32 outputs flush per piece*/ = nullptr) {
         if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU>(stage, ep, mbase, nbase, M, N, lane, gap);
         else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU>(stage, ep, mbase, nbase, M, N, lane, gap);
         else run_act<SHG_ACT_NONE>(stage, ep, mbase, nbase, M, N, lane, gap);
     }
     template <int ACT>
-    __device__ static void run_act(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
+    __device__ __forceinline__ static void run_act(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                    int64_t N, int lane, int gap) {
         const bool drop = ep.drop_thr != 0;
         if (ep.atomic) {                               // one 256-byte row segment per wave instruction
@@ -698,8 +759,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
     // epilogue: stage 64 x 64 fp32 pieces of the wave's result in LDS (the operand tiles are dead after
     // the last barrier of the loop) and write whole row segments
     float* stg = reinterpret_cast<float*>(smem) + wave * (64 * STG_LD);
-#pragma unroll
-    for (int h = 0; h < IM / 4; ++h) {
+    // (one 64-row piece per call with a compile-time piece index: a `#pragma unroll` loop over the pieces is left rolled once
+    //  the row writer is large, and acc[4 h + i] with a run-time h puts the accumulators into scratch)
+    auto piece = [&](auto h_c) {
+        constexpr int h = decltype(h_c)::value;
         if (h) __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -708,7 +771,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(SrcA sa, SrcB sb, Ep
                 *reinterpret_cast<f32x4*>(stg + (16 * i + li) * STG_LD + 16 * j + 4 * g) = acc[4 * h + i][j];
         __syncthreads();
         RowWriter<TC>::run(stg, ep, m0 + wr * (16 * IM) + 64 * h, n0 + 64 * wc, M, N, lane);
-    }
+    };
+    static_assert(IM == 4 || IM == 8, "one or two 64-row pieces per wave");
+    piece(std::integral_constant<int, 0>{});
+    if constexpr (IM == 8) piece(std::integral_constant<int, 1>{});
 }
 
 
@@ -1253,8 +1319,11 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     float* stg1 = stg0 + 64 * STG_LD;                                               // its right block (columns 128 + 64 q ..)
     const int half = wc & 1;
     float csum_carry[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bias-gradient sums of both A halves (same columns)
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    // (the A half is a compile-time constant of the lambda: as a `#pragma unroll` loop the compiler stops unrolling it once the
+    //  row writer grows past its size threshold, indexes acc[a] dynamically and moves the whole accumulator array into scratch -
+    //  528 bytes per lane, zero-filled before the main loop)
+    auto epilogue_half = [&](auto a_c) {
+        constexpr int a = decltype(a_c)::value;
         if (a) __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1264,8 +1333,27 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
                 for (int j = 0; j < 2; ++j)
                     *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li) * STG_LD + 32 * half + 16 * j + 4 * g) = acc[a][b][i][j];
         __syncthreads();
-        RowWriter<TC>::run(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane, 0,
-                           csum_carry);
+        RowWriter<TC>::template run<!SK>(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane, 0,
+                                         csum_carry);
+    };
+    if constexpr (SK) {                              // (the stream-K body keeps the loop form: its register allocation is at the limit
+#pragma unroll                                       //  and this form spills least - 168 against 244 bytes per lane)
+        for (int a = 0; a < 2; ++a) {
+            if (a) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li) * STG_LD + 32 * half + 16 * j + 4 * g) = acc[a][b][i][j];
+            __syncthreads();
+            RowWriter<TC>::template run<false>(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane, 0,
+                                               csum_carry);
+        }
+    } else {
+        epilogue_half(std::integral_constant<int, 0>{});
+        epilogue_half(std::integral_constant<int, 1>{});
     }
     if (ep.csum) RowWriter<TC>::flush_csum(csum_carry, ep, n0 + 128 * half + 64 * (wc >> 1), N, lane);
     if constexpr (SK) __syncthreads();               // the staging area is the next segment's first operand buffer
@@ -1554,7 +1642,8 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
         return dtype_ab == SHG_F32 ? gemm_dispatch<float, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st)
                                    : gemm_dispatch<bf16_t, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
     }
-    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0, nullptr, nullptr, dthr, dscale, seed_state, stream_id};
+    Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0, nullptr, nullptr, dthr, dscale, seed_state, stream_id,
+                        tuning(TUNE_EPILOGUE_SIDE) ? 0 : 1};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
 }
 
@@ -1671,7 +1760,8 @@ extern "C" int shg_gemm_dact(const void* dy, const void* w, void* dx, const void
         Epilogue<float> ep{(float*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const float*)pre, dbias, thr, scale, seed_state, stream_id};
         return gemm_dispatch<float, float>(dy, w, ep, M, N, K, lda, ldb, 1, 0, st);
     }
-    Epilogue<bf16_t> ep{(bf16_t*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const bf16_t*)pre, dbias, thr, scale, seed_state, stream_id};
+    Epilogue<bf16_t> ep{(bf16_t*)dx, ldc, nullptr, nullptr, act, 0, 1, nullptr, 0, (const bf16_t*)pre, dbias, thr, scale, seed_state, stream_id,
+                        tuning(TUNE_EPILOGUE_SIDE) ? 0 : 1};
     return gemm_dispatch<bf16_t, bf16_t>(dy, w, ep, M, N, K, lda, ldb, 1, 0, st);
 }
 

@@ -45,12 +45,16 @@ __device__ __forceinline__ double warmup_linear(double x, double warmup) {
     return y > 0.0 ? y : 0.0;
 }
 
+// UNROLL: independent 16-byte vectors per lane and iteration (1, 2 or 4); NT_MAIN: non-temporal loads of p / g / m / v and stores
+// of p / m / v; NT_AUX: non-temporal stores of the zeroed gradient and of the bf16 shadow as well ("bertadam_mode" tuning switch:
+// bit 0 UNROLL 2, bit 3 UNROLL 4, bit 1 NT_AUX, bit 2 switches NT_MAIN off)
+template <int UNROLL, bool NT_MAIN, bool NT_AUX>
 __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        bf16_t* __restrict__ shadow, int64_t n,
                                                        const float* __restrict__ grad_norm, float max_norm, float lr,
                                                        float warmup, int64_t t_total, float b1, float b2, float eps,
-                                                       float wd, const int64_t* __restrict__ step_state, int mode, int zero_g) {
+                                                       float wd, const int64_t* __restrict__ step_state, int zero_g) {
     float clip = 1.f;
     if (grad_norm && max_norm > 0.f) clip = fminf(max_norm / (grad_norm[0] + 1e-6f), 1.f);
     double lr_d = (double)lr;
@@ -79,19 +83,25 @@ __global__ __launch_bounds__(256) void bertadam_kernel(float* __restrict__ p, fl
     bf16x4* s4 = reinterpret_cast<bf16x4*>(shadow);
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; mode && i + stride < n4; i += 2 * stride) {
-        const int64_t k = i + stride;
-        f32x4 pa = __builtin_nontemporal_load(p4 + i), ga = __builtin_nontemporal_load(g4 + i);
-        f32x4 ma = __builtin_nontemporal_load(m4 + i), va = __builtin_nontemporal_load(v4 + i);
-        f32x4 pb = __builtin_nontemporal_load(p4 + k), gb = __builtin_nontemporal_load(g4 + k);
-        f32x4 mb = __builtin_nontemporal_load(m4 + k), vb = __builtin_nontemporal_load(v4 + k);
-        bf16x4 sa, sb;
-        update(pa, ga, ma, va, sa);
-        update(pb, gb, mb, vb, sb);
-        __builtin_nontemporal_store(pa, p4 + i); __builtin_nontemporal_store(ma, m4 + i); __builtin_nontemporal_store(va, v4 + i);
-        __builtin_nontemporal_store(pb, p4 + k); __builtin_nontemporal_store(mb, m4 + k); __builtin_nontemporal_store(vb, v4 + k);
-        if (zero_g) { g4[i] = zero4; g4[k] = zero4; }    // next step's weight-gradient GEMMs accumulate from zero
-        if (shadow) { s4[i] = sa; s4[k] = sb; }           // the bf16 operands are read again by the next step's GEMMs
+    auto ld = [](const f32x4* q) { return NT_MAIN ? __builtin_nontemporal_load(q) : *q; };
+    auto st = [](f32x4 x, f32x4* q) { if (NT_MAIN) __builtin_nontemporal_store(x, q); else *q = x; };
+    for (; UNROLL > 1 && i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        f32x4 pa[UNROLL], ga[UNROLL], ma[UNROLL], va[UNROLL];
+        bf16x4 sa[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t k = i + u * stride;
+            pa[u] = ld(p4 + k); ga[u] = ld(g4 + k); ma[u] = ld(m4 + k); va[u] = ld(v4 + k);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) update(pa[u], ga[u], ma[u], va[u], sa[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t k = i + u * stride;
+            st(pa[u], p4 + k); st(ma[u], m4 + k); st(va[u], v4 + k);
+            if (zero_g) { if (NT_AUX) __builtin_nontemporal_store(zero4, g4 + k); else g4[k] = zero4; }   // next step's weight gradients accumulate from zero
+            if (shadow) { if (NT_AUX) __builtin_nontemporal_store(sa[u], s4 + k); else s4[k] = sa[u]; }   // bf16 operands of the next step's GEMMs
+        }
     }
     for (; i < n4; i += stride) {
         f32x4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
@@ -156,8 +166,16 @@ extern "C" int shg_bertadam_arena(float* param, float* grad, float* m, float* v,
         const int adam_mode = (int)tuning(TUNE_BERTADAM_MODE);
         const int64_t adam_blocks = std::max<int64_t>(1, tuning(TUNE_BERTADAM_BLOCKS));   // measured: 2 048 .. 8 192 blocks 4.3-4.5 TB/s, 16 384 4.8
         const int64_t blocks = std::min<int64_t>((n / 4 + 255) / 256 + 1, adam_blocks);
-        hipLaunchKernelGGL(bertadam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, m, v, (bf16_t*)shadow_bf16,
-                           n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state, adam_mode, (bump_step >> 1) & 1);
+#define SHG_ADAM(U, NM, NA)                                                                                                   \
+    hipLaunchKernelGGL((bertadam_kernel<U, NM, NA>), dim3((unsigned)blocks), dim3(256), 0, st, param, grad, m, v,           \
+                       (bf16_t*)shadow_bf16, n, grad_norm, max_norm, lr, warmup, t_total, b1, b2, eps, weight_decay, step_state, \
+                       (bump_step >> 1) & 1)
+        const int unroll = (adam_mode & 8) ? 4 : ((adam_mode & 1) ? 2 : 1);
+        const bool nt_main = !(adam_mode & 4), nt_aux = (adam_mode & 2) != 0;
+        if (unroll == 4) { if (nt_main) { if (nt_aux) SHG_ADAM(4, true, true); else SHG_ADAM(4, true, false); } else SHG_ADAM(4, false, false); }
+        else if (unroll == 2) { if (nt_main) { if (nt_aux) SHG_ADAM(2, true, true); else SHG_ADAM(2, true, false); } else SHG_ADAM(2, false, false); }
+        else SHG_ADAM(1, false, false);
+#undef SHG_ADAM
     }
     if (bump_step & 1) hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(1), 0, st, step_state, (int64_t)1);
     return check_launch("bertadam_arena");
