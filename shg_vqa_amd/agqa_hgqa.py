@@ -501,8 +501,8 @@ def main(argv=None):
     valid = get_tuple(args.valid, args.batch_size, shuffle=False, drop_last=False) if args.valid else None
     agqa = AGQA(args, train_tuple=train, valid_tuple=valid)
     if multi:
-        from .ddp import GradReducer
-        agqa.world = GradReducer(engine().grad_arena)
+        from .ddp import GradReducer, default_wire_dtype
+        agqa.world = GradReducer(engine().grad_arena, grad_dtype=default_wire_dtype())
         engine().grad_ready_hook = agqa.world.on_grad
     if args.load is not None:
         agqa.load(args.load)

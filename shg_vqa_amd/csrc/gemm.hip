@@ -326,14 +326,15 @@ template <> struct RowWriter<bf16_t> {
     // of going to memory; the caller flushes them once with flush_csum (fewer atomics on the shared bias-gradient vector)
     // SIDE: compile the whole-tile forms that read a second operand (accumulate / activation backward) with their loads up front
     // (off in the stream-K convolution kernel, which has no register to spare and never uses them)
-    template <bool SIDE = true>
+    // ROWS: rows of the staged piece (64, or 48 for the 192-row tile of the 8-phase kernel)
+    template <bool SIDE = true, int ROWS = 64>
     __device__ __forceinline__ static void run(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0, float* csum_carry = nullptr) {
-        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU, SIDE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
-        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU, SIDE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
-        else run_act<SHG_ACT_NONE, SIDE>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU, SIDE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU, SIDE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        else run_act<SHG_ACT_NONE, SIDE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
     }
-    template <int ACT, bool SIDE>
+    template <int ACT, bool SIDE, int ROWS>
     __device__ __forceinline__ static void run_act(const float* stage, const Epilogue<bf16_t>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                    int64_t N, int lane, int gap, float* csum_carry) {
         float csum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -358,17 +359,18 @@ template <> struct RowWriter<bf16_t> {
         }
         // the plain case (bias + activation, whole 16-byte vectors, all 64 rows inside the matrix): the eight passes' LDS reads
         // are issued together and nothing but the activation sits between them and the stores
-        if (!ep.gpre && !ep.csum && !ep.accumulate && !drop && !ep.pre && !ep.crow && ep.vec_ok && nv == 8 && mbase + 64 <= M) {
-            f32x4 va[8], vb[8];
+        constexpr int NP = ROWS / 8;                     // row passes: a wave writes 8 rows per pass
+        if (!ep.gpre && !ep.csum && !ep.accumulate && !drop && !ep.pre && !ep.crow && ep.vec_ok && nv == 8 && mbase + ROWS <= M) {
+            f32x4 va[NP], vb[NP];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const int row = 8 * p + (lane >> 3);
                 va[p] = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
                 vb[p] = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col + 4);
             }
             bf16_t* dst0 = ep.c + (mbase + (lane >> 3)) * ep.ldc + n;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 bf16x8 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -383,17 +385,19 @@ template <> struct RowWriter<bf16_t> {
         // `C = (A.B) * act'(gpre)` with the bias-gradient column sums.  Their global READS (old C / the saved pre-activation) are
         // all issued before the first row pass - in the general loop below each pass waits for its own load, eight dependent L2
         // round trips per call - with constant indices only, so that the eight vectors stay in registers (32 VGPRs)
-        if (SIDE && !ep.no_side && (ep.accumulate || ep.gpre) && !(ep.accumulate && ep.gpre) && !drop && !ep.pre && !ep.crow && ep.vec_ok && nv == 8 && mbase + 64 <= M) {
+        if (SIDE && !ep.no_side && (ep.accumulate || ep.gpre) && !(ep.accumulate && ep.gpre) && !drop && !ep.pre && !ep.crow && ep.vec_ok && nv == 8 && mbase + ROWS <= M) {
             bf16_t* dst0 = ep.c + (mbase + (lane >> 3)) * ep.ldc + n;
             const bf16_t* src0 = ep.gpre ? ep.gpre + (mbase + (lane >> 3)) * N + n : dst0;
             const int64_t lds_ = ep.gpre ? N : ep.ldc;
             const bool dact = ep.gpre != nullptr;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {            // four row passes at a time: 16 VGPRs of loaded vectors in flight
-                bf16x8 s0 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h) * lds_);
-                bf16x8 s1 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h + 8) * lds_);
-                bf16x8 s2 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h + 16) * lds_);
-                bf16x8 s3 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(32 * h + 24) * lds_);
+            for (int h = 0; h < 2; ++h) {            // half of the row passes at a time: 12-16 VGPRs of loaded vectors in flight
+                constexpr int PH = NP / 2;                                   // 4 (64 rows) or 3 (48 rows)
+                bf16x8 s0 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(8 * PH * h) * lds_);
+                bf16x8 s1 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(8 * PH * h + 8) * lds_);
+                bf16x8 s2 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(8 * PH * h + 16) * lds_);
+                bf16x8 s3 = s2;
+                if (PH == 4) s3 = *reinterpret_cast<const bf16x8*>(src0 + (int64_t)(8 * PH * h + 24) * lds_);
                 auto pass = [&](int p, const bf16x8& side) {
                     const int row = 8 * p + (lane >> 3);
                     const f32x4 a = *reinterpret_cast<const f32x4*>(stage + row * STG_LD + col);
@@ -416,13 +420,13 @@ template <> struct RowWriter<bf16_t> {
                 // (scheduling fences: left alone, the scheduler gathers the LDS reads of all passes at the top - 64 more live
                 //  registers beside the second half's accumulators - and the kernel spills 528 bytes per lane)
                 __builtin_amdgcn_sched_barrier(0);
-                pass(4 * h, s0);
+                pass(PH * h, s0);
                 __builtin_amdgcn_sched_barrier(0);
-                pass(4 * h + 1, s1);
+                pass(PH * h + 1, s1);
                 __builtin_amdgcn_sched_barrier(0);
-                pass(4 * h + 2, s2);
+                pass(PH * h + 2, s2);
                 __builtin_amdgcn_sched_barrier(0);
-                pass(4 * h + 3, s3);
+                if (PH == 4) pass(PH * h + 3, s3);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ep.csum) {
@@ -436,7 +440,7 @@ template <> struct RowWriter<bf16_t> {
             return;
         }
 #pragma unroll 2
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int row = 8 * p + (lane >> 3);
             const int64_t m = mbase + row;
             if (m >= M || n >= N) continue;
@@ -520,20 +524,20 @@ template <> struct RowWriter<bf16_t> {
 };
 template <> struct RowWriter<float> {
     __device__ static void flush_csum(float*, const Epilogue<float>&, int64_t, int64_t, int, int = 0) {}
-    template <bool SIDE = true>
+    template <bool SIDE = true, int ROWS = 64>
     __device__ __forceinline__ static void run(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                int64_t N, int lane, int gap = 0, float* /*csum_carry: fp32 outputs flush per piece*/ = nullptr) {
-        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU>(stage, ep, mbase, nbase, M, N, lane, gap);
-        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU>(stage, ep, mbase, nbase, M, N, lane, gap);
-        else run_act<SHG_ACT_NONE>(stage, ep, mbase, nbase, M, N, lane, gap);
+        if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap);
+        else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap);
+        else run_act<SHG_ACT_NONE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap);
     }
-    template <int ACT>
+    template <int ACT, int ROWS>
     __device__ __forceinline__ static void run_act(const float* stage, const Epilogue<float>& ep, int64_t mbase, int64_t nbase, int64_t M,
                                    int64_t N, int lane, int gap) {
         const bool drop = ep.drop_thr != 0;
         if (ep.atomic) {                               // one 256-byte row segment per wave instruction
             const int64_t n = nbase + lane + (lane >= 32 ? gap : 0);
-            for (int row = 0; row < 64; ++row) {
+            for (int row = 0; row < ROWS; ++row) {
                 const int64_t m = mbase + row;
                 if (m < M && n < N) atomicAdd(ep.c + m * ep.ldc + n, stage[row * STG_LD + lane]);
             }
@@ -551,7 +555,7 @@ template <> struct RowWriter<float> {
                 if (r < nv) bias4[r] = ep.bias[n + r];
         }
 #pragma unroll 2
-        for (int p = 0; p < 16; ++p) {
+        for (int p = 0; p < ROWS / 4; ++p) {
             const int row = 4 * p + (lane >> 4);
             const int64_t m = mbase + row;
             if (m >= M || n >= N) continue;
@@ -1043,10 +1047,19 @@ __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_
 // segment loop lives in gemm8_sk_kernel, which re-reads the kernel arguments from the kernarg segment for every segment:
 // with the loop in here every argument (three operand / epilogue structs) stayed live across the whole pipelined main loop
 // and 95 SGPRs + 48 VGPRs were spilled (196 B of scratch per lane).
-template <typename TC, typename SrcA, typename SrcB, bool SK = false>
+// TM: rows of the tile, 256 or 192.  The 192-row form (K-major A only) exists for the 12 576-row problems with 768 / 1 536
+// output columns: 150 / 300 tiles of 256 x 256 fill 59 % of the 256 CUs in their (last) round, 198 / 396 tiles of 192 x 256 fill
+// 77 % at three quarters of the work per tile.  The A operand is staged row-linearly (64 rows per direct-to-LDS instruction of the
+// workgroup), so a 96-row half is one and a half instructions: the middle instruction's rows 64-95 belong to half 0 and are
+// issued by waves 0-3, rows 96-127 to half 1 by waves 4-7 - which is why the counted vmcnt waits differ between the two wave
+// groups (6 outstanding loads for waves 0-3, 5 for waves 4-7, see below).  A wave owns 48 rows (three 16-row blocks) of each half.
+template <typename TC, typename SrcA, typename SrcB, bool SK = false, int TM = 256>
 __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K, int grid_m, StreamK sk,
                                            const int bx, const int by, const int gx, const int gy, const int seg = 0) {
     static_assert(!SrcA::DYN, "only the B operand may gather per K-tile");
+    static_assert(TM == 256 || (TM == 192 && SrcA::KMAJOR && !SK), "the 192-row tile needs a K-major A operand");
+    constexpr int NI = TM / 64;                      // 16-row blocks per wave and A half
+    constexpr int HALF = TM / 2, WROWS = TM / 4;     // rows per A half / per wave and half
     using T = bf16_t;
     using TL = Tile64<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1082,7 +1095,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         if (nk <= 0) return false;
     }
     const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
-    const int64_t m0 = bm * 256, n0 = bn * 256;
+    const int64_t m0 = bm * TM, n0 = bn * 256;
     sa.r0 = m0;
     sb.r0 = n0;
 
@@ -1102,13 +1115,13 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         for (int u = 0; u < 3; ++u) dpos[u] = *sb.dyn_ptr(tid, (kb + u) * BK);
     }
 
-    f32x4 acc[2][2][4][2];                           // [A half][B half][16-row block][16-col block]
+    f32x4 acc[2][2][NI][2];                          // [A half][B half][16-row block][16-col block]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1130,6 +1143,15 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     auto stage_a = [&](int buf, int h, int64_t kt) {
         if (kt >= nk) return;
         char* base = smem + buf * STAGE_BYTES + 64 * wave_u * 16;
+        if constexpr (TM == 192) {
+            // rows 0-63: instruction 0, rows 64-127: instruction 1 (waves 0-3 hold its rows 64-95, waves 4-7 rows 96-127),
+            // rows 128-191: instruction 2; half 0 = rows 0-95, half 1 = rows 96-191
+            const int whole = h ? 2 : 0;
+            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(whole, (kb + kt) * BK) + offa[whole]), (lds_ptr)(base + NTHR * whole * 16), 16, 0, 0);
+            if ((wave_u >= 4) == (h == 1))
+                __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(1, (kb + kt) * BK) + offa[1]), (lds_ptr)(base + NTHR * 1 * 16), 16, 0, 0);
+            return;
+        }
         const bool rag = RAGGED_OK && tail && (kb + kt) == nk_all - 1;          // wave-uniform
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
@@ -1159,12 +1181,16 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         stage_b(0, 0, 0, d0); stage_a(0, 0, 0); stage_b(0, 1, 0, d0); stage_a(0, 1, 0);
         stage_b(1, 0, 1, d1); stage_a(1, 0, 1); stage_b(1, 1, 1, d1);
     }
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // three half-tile stages may stay in flight: 2 + 2 + 2 instructions - with the 192-row tile an A half is two instructions for
+    // one wave group and one for the other (stage_a), i.e. 6 for waves 0-3 (A half 0 of K-tile 1 / t + 2 in flight) and 5 for waves 4-7
+    if (nk > 1) {
+        if (TM == 192 && wave_u >= 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // second wave group runs one barrier behind
 
-    Frag<T> fa[4][2], fb0[2][2], fb1[2][2];
+    Frag<T> fa[NI][2], fb0[2][2], fb1[2][2];
     // contraction-strided operands: per-lane LDS addresses of the wave's column blocks in buffer 0, half 0
     uint32_t tra[4] = {0, 0, 0, 0}, trb[2] = {0, 0};
     if constexpr (!AK) {
@@ -1177,8 +1203,8 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     }
 #define SHG_G8_RA(H)                                                                                              \
     if constexpr (AK) {                                                                                           \
-        const char* t_ = X + (2 * (H) + wr) * TL::BYTES;                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+        const char* t_ = X + ((H) * HALF + wr * WROWS) * TL::ROWB;     /* (row-linear: 64 rows per Tile64) */     \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                            \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) fa[i][ks] = lds_row_frag<T>(t_, 16 * i + li, 32 * ks, g); \
     } else {                                                                                                      \
         fa[0][0] = tr_frag<(H) * 2 * TL::BYTES, 0>(tra[0] + xoff); fa[0][1] = tr_frag<(H) * 2 * TL::BYTES, 1>(tra[0] + xoff); \
@@ -1199,7 +1225,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
 #define SHG_G8_MMA(AH, BH, FB)                                               \
     __builtin_amdgcn_s_setprio(1);                                           \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                         \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)                       \
             _Pragma("unroll") for (int j = 0; j < 2; ++j) mma(acc[AH][BH][i][j], FB[j][ks], fa[i][ks]); \
     __builtin_amdgcn_s_setprio(0);
 
@@ -1218,7 +1244,8 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         stage_a(cur ^ 1, 1, kt + 1);
         __builtin_amdgcn_sched_barrier(0);
         // the B0 reads (issued first) have returned: B0 may be restaged by the other wave group after the barrier
-        if constexpr (AK) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        if constexpr (AK && NI == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // (the 2 NI reads of A may be outstanding)
+        else if constexpr (AK) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1245,8 +1272,10 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         __builtin_amdgcn_s_barrier();
         // ---- phase 4: quadrant (A1, B0); K-tile t+1 is complete after this wait
         stage_b(cur, 1, kt + 2, dyn_cur);
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) {
+            if (TM == 192 && wave_u >= 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (SrcB::DYN) {                    // the position fetched in phase 1 has landed (older than the 6)
             asm volatile("" : "+v"(dnext));
             dyn_cur = sb.dyn_off(tid, dnext);
@@ -1275,7 +1304,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR] = acc[a][b][i][j];
             __threadfence();
@@ -1305,7 +1334,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc[a][b][i][j] += slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR];
         }
@@ -1326,15 +1355,15 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         constexpr int a = decltype(a_c)::value;
         if (a) __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li) * STG_LD + 32 * half + 16 * j + 4 * g) = acc[a][b][i][j];
         __syncthreads();
-        RowWriter<TC>::template run<!SK>(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane, 0,
-                                         csum_carry);
+        RowWriter<TC>::template run<!SK, WROWS>(half ? stg1 : stg0, ep, m0 + HALF * a + WROWS * wr, n0 + 128 * half + 64 * (wc >> 1), M, N,
+                                                lane, 0, csum_carry);
     };
     if constexpr (SK) {                              // (the stream-K body keeps the loop form: its register allocation is at the limit
 #pragma unroll                                       //  and this form spills least - 168 against 244 bytes per lane)
@@ -1361,11 +1390,11 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     return true;
 }
 
-template <typename TC, typename SrcA, typename SrcB, bool SK = false>
+template <typename TC, typename SrcA, typename SrcB, bool SK = false, int TM = 256>
 __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int64_t K,
                                                     int grid_m, StreamK sk) {
     static_assert(!SK, "stream-K launches go through gemm8_sk_kernel");
-    gemm8_body<TC, SrcA, SrcB, false>(sa, sb, ep, M, N, K, grid_m, sk, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+    gemm8_body<TC, SrcA, SrcB, false, TM>(sa, sb, ep, M, N, K, grid_m, sk, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
 }
 
 // Stream-K launch: all arguments in ONE struct, read afresh from the kernarg segment (scalar loads through a pointer the
@@ -1470,6 +1499,21 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
                 hipLaunchKernelGGL(kern, dim3(STREAMK_WGS), dim3(512), lds, st, G8SkArgs<TC, SrcA, SrcB>{sa, sb, ep, M, N, K, tile_order(gm, gn), sk});
                 return check_launch(what);
             }
+        }
+    }
+    // 192-row tiles (plain K-major A, no split): chosen when fewer "tile rounds x work per tile" cover the problem on 256 CUs -
+    // 12 576 x 768: 150 tiles in one round at 59 % fill -> 198 tiles at three quarters of the work each; x 1 536: two rounds ->
+    // two rounds of 0.75; x 2 304 / x 3 072 stay (594 / 792 tiles would need a third / fourth round).  "gemm8_tile_m" forces 256 / 192.
+    if constexpr (std::is_same<SrcA, PlainSrc<bf16_t, true>>::value && ALLOW_SK == 0) {
+        const int64_t gm192 = (M + 191) / 192, tiles192 = gm192 * gn, want = tuning(TUNE_GEMM8_TILE_M);
+        const int64_t cost256 = 4 * ((tiles + 255) / 256), cost192 = 3 * ((tiles192 + 255) / 256);
+        if (split == 1 && !ep.atomic && tiles192 <= 0x7fffffff && (want == 192 || (want == 0 && cost192 < cost256))) {
+            auto kern = gemm8_kernel<TC, SrcA, SrcB, false, 192>;
+            static std::atomic<uint64_t> raised192{0};
+            raise_lds_limit(raised192, reinterpret_cast<const void*>(kern), (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles192, 1), dim3(512), lds, st, sa, sb, ep, M, N, K,
+                               tile_order(gm192, gn), StreamK{nullptr, nullptr, 0, 100});
+            return check_launch(what);
         }
     }
     auto kern = gemm8_kernel<TC, SrcA, SrcB, false>;

@@ -29,7 +29,15 @@ Design for MI355X / xGMI:
     and needs no extra averaging pass;
   * optional bf16 wire format (grad_dtype=torch.bfloat16): a bucket is cast into a bf16 staging
     buffer, reduced, and cast back - half the bytes on the links (0.58 GB instead of 1.16 GB per step)
-    at bf16 summation accuracy.  Off by default (fp32 = the reference's arithmetic).
+    at bf16 summation accuracy.  fp32 (= the reference's arithmetic) unless asked for, except with two ranks
+    (default_wire_dtype);
+  * what a slow collective does to the weight gradients queued behind it on W: the executor's flush issues ALL grouped
+    weight-gradient launches of a flush first and only then reports their parameters (Engine.flush_native_wgrads), so a
+    bucket's collective sits behind the last group of ITS flush and delays only the groups of LATER flushes - never the
+    input-gradient chain on the main stream, which does not wait for W before the gradient norm.  W then carries ~3 ms of
+    grouped launches plus the collectives (6.7 ms at 8 ranks, 7.6 ms at 4, 7.6 ms bf16 at 2) inside an ~11 ms backward
+    window.  A dedicated communication stream would free W but costs a fifth hardware queue (measured: +3.5-4 ms per step on
+    one rank), so it is not used.
 """
 import bisect
 
@@ -60,6 +68,16 @@ def init_process_group(device, backend="nccl", **kw):
     if backend == "nccl":
         kw.setdefault("device_id", torch.device(device))
     dist.init_process_group(backend, **kw)
+
+
+def default_wire_dtype(world=None):
+    """Wire format of the gradient exchange when none is asked for: fp32 (the reference's arithmetic), except with TWO ranks -
+    one xGMI link carries the whole 1.156 GB exchange there (15 ms per step in fp32 against an 11 ms backward window, DESIGN.md
+    section 5), so two ranks default to bf16 on the wire (7.6 ms, hidden)."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    rccl = dist.is_initialized() and dist.get_backend() == "nccl"        # (the gloo rehearsal path stays fp32)
+    return torch.bfloat16 if (world == 2 and rccl) else None
 
 
 def param_aligned_bounds(n, per, spans=None):

@@ -123,3 +123,10 @@ def test_reducer_raises_when_a_step_writes_differently_from_the_learning_step():
     r.on_grad(0, 32)
     with pytest.raises(RuntimeError, match="written"):
         r.finish()                                         # bucket 1 was never written
+
+
+def test_default_wire_format_is_fp32_except_for_two_rccl_ranks():
+    """ddp.default_wire_dtype: bf16 on the wire only where one xGMI link carries the whole exchange (two ranks, RCCL)."""
+    from shg_vqa_amd import ddp
+    assert ddp.default_wire_dtype(1) is None and ddp.default_wire_dtype(8) is None
+    assert ddp.default_wire_dtype(2) is None          # no process group here (and gloo never switches)

@@ -652,6 +652,83 @@ def test_gemm_8phase_kernel_is_exact_and_race_free_on_integer_data(K):
     assert torch.equal(out.cpu(), a @ b.t())
 
 
+def test_gemm_8phase_192_row_tile(K):
+    """The 192 x 256 tile of the 8-phase kernel (gemm.hip: TM = 192; chosen for the 12 576-row problems with 768 / 1 536 output
+    columns): forced through the "gemm8_tile_m" switch on shapes with ragged last row tiles (rows % 192 = 96 / 48 / 8 / 0),
+    both operand forms, every epilogue - against the same call on the 256-row tile (bit-identical: the contraction order of a
+    tile does not depend on its height) and against fp32 references; plus exact small-integer data over 6 launches with an
+    odd and an even number of K-tiles (stale or early LDS reads of the asymmetric half-tile staging would show)."""
+    from shg_vqa_amd import _lib
+    gen = torch.Generator().manual_seed(192)
+
+    def both(fn):
+        outs = []
+        for tm in (256, 192):
+            _lib.set_tuning("gemm8_tile_m", tm)
+            try:
+                outs.append(fn())
+            finally:
+                _lib.set_tuning("gemm8_tile_m", 0)
+        return outs
+
+    for (M, N, Kd, bkm) in [(12576, 768, 768, True), (12576, 1536, 768, True), (12576, 768, 3072, False), (12576, 768, 2304, False),
+                            (4104, 3080, 192, True), (3848, 2048, 448, False), (6144, 2304, 128, True)]:
+        a = torch.randn(M, Kd, generator=gen).bfloat16().to(DEV)
+        b = (torch.randn((N, Kd) if bkm else (Kd, N), generator=gen) / math.sqrt(Kd)).bfloat16().to(DEV)
+        bias = torch.randn(N, generator=gen).to(DEV)
+        ref = a.float() @ (b.float().t() if bkm else b.float())
+        # plain bf16 / fp32 outputs with bias
+        for odt in (torch.bfloat16, torch.float32):
+            o256, o192 = both(lambda: K.gemm(a, b, torch.empty(M, N, dtype=odt, device=DEV), bias, True, bkm))
+            assert torch.equal(o256, o192), (M, N, Kd, bkm, odt)
+            _assert_close(o192, ref + bias, torch.bfloat16, scale=2.0)
+        # C += A.B on a bf16 residual gradient
+        c0 = torch.randn(M, N, generator=gen).bfloat16().to(DEV)
+        o256, o192 = both(lambda: K.gemm(a, b, c0.clone(), None, True, bkm, accumulate=True))
+        assert torch.equal(o256, o192)
+        _assert_close(o192, ref + c0.float(), torch.bfloat16, scale=2.0)
+        if bkm:
+            # forward epilogue: bias + GELU with the pre-activation saved
+            def fwd():
+                out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+                pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+                K.gemm_act(a, b, out, bias, 1, pre)
+                return torch.stack([out, pre])
+            o256, o192 = both(fwd)
+            assert torch.equal(o256, o192)
+            _assert_close(o192[0], F.gelu(ref + bias), torch.bfloat16, scale=2.0)
+        else:
+            # input-gradient epilogue: activation backward + bias-gradient column sums
+            pre = torch.randn(M, N, generator=gen).bfloat16().to(DEV)
+
+            def bwd():
+                dx = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+                db = torch.zeros(N, device=DEV)
+                K.gemm_dact(a, b, dx, pre, db, 1)
+                return dx, db
+            (d256, b256), (d192, b192) = both(bwd)
+            assert torch.equal(d256, d192)
+            p32 = pre.float().requires_grad_(True)
+            F.gelu(p32).backward(ref)
+            _assert_close(d192, p32.grad, torch.bfloat16, scale=2.0)
+            assert torch.allclose(b192.double().cpu(), d192.double().cpu().sum(0), rtol=1e-4, atol=2e-3 * math.sqrt(M))
+    # exact integers, odd and even K-tile counts, repeated
+    for Kd in (64 * 7, 4096):
+        M, N = 12576, 768
+        a = torch.randint(-3, 4, (M, Kd), generator=gen).float()
+        b = torch.randint(-2, 3, (N, Kd), generator=gen).float()
+        ref = (a.to(DEV) @ b.to(DEV).t()).cpu()
+        aa, bb, bt = a.bfloat16().to(DEV), b.bfloat16().to(DEV), b.t().contiguous().bfloat16().to(DEV)
+        _lib.set_tuning("gemm8_tile_m", 192)
+        try:
+            for it in range(6):
+                out = torch.empty(M, N, device=DEV)
+                K.gemm(aa, bb if it % 2 == 0 else bt, out, None, True, it % 2 == 0)
+                assert torch.equal(out.cpu(), ref), (Kd, it)
+        finally:
+            _lib.set_tuning("gemm8_tile_m", 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", [1, 2])
 def test_gemm_dact_fuses_activation_backward_and_bias_gradient(K, dtype, act):
