@@ -200,18 +200,23 @@ int shg_colsum_accumulate(const void* x, int dtype, int64_t rows, int cols, int6
  *   o [B, Sq, H*64] contiguous; lse [B, H, Sq] fp32 (log-sum-exp of the scaled, masked scores).
  *   mask: SHG_MASK_KEY -> fp32 [B, Sk]; SHG_MASK_FULL -> fp32 [Sq, Sk]; -inf allowed.
  * bwd recomputes the probabilities from lse; delta [B,H,Sq] fp32 is workspace.
+ * Dropout on the probabilities (modeling_capsbert.py:404-406, p = attention_probs_dropout_prob; transformer.py:219-229): the forward
+ * call draws the keep decisions and writes them to keep_mask as lane masks (shg_attention_keep_mask_bytes(B, H, Sq, Sk) bytes,
+ * 128-byte aligned, caller-owned; layout in csrc/attention.hip); the backward call of the same attention reads them instead of
+ * re-drawing.  keep_mask is required when p_drop > 0 and ignored (may be NULL) otherwise.
  */
+int64_t shg_attention_keep_mask_bytes(int B, int H, int Sq, int Sk);
 int shg_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H,
                       int Sq, int Sk, int64_t q_bstride, int64_t q_sstride, int64_t k_bstride, int64_t k_sstride,
                       int64_t v_bstride, int64_t v_sstride, int mask_kind, const float* mask, float scale,
-                      float p_drop, const uint64_t* seed_state, uint64_t stream_id, void* stream);
+                      float p_drop, const uint64_t* seed_state, uint64_t stream_id, uint64_t* keep_mask, void* stream);
 int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, void* dk, void* dv, int dtype, int B, int H,
                       int Sq, int Sk, int64_t q_bstride, int64_t q_sstride, int64_t k_bstride, int64_t k_sstride,
                       int64_t v_bstride, int64_t v_sstride, int64_t dq_bstride, int64_t dq_sstride,
                       int64_t dk_bstride, int64_t dk_sstride, int64_t dv_bstride, int64_t dv_sstride,
                       int mask_kind, const float* mask, float scale, float p_drop, const uint64_t* seed_state,
-                      uint64_t stream_id, void* stream);
+                      uint64_t stream_id, const uint64_t* keep_mask, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM on the matrix cores:  C[M,N] = A . B (+ bias[N]), fp32 accumulation.

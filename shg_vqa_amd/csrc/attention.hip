@@ -22,6 +22,15 @@
 //     lane) instead of one global load per score element; the tail test (key >= Sk) only exists in the last tile;
 //   * the output accumulators are only rescaled when some running maximum actually moved (wave-uniform test).
 //
+// Dropout: the forward kernel draws the keep decisions (counter-based hash, common.h) and WRITES them out as lane masks: for a
+// wave's block of 16 queries and a tile of 64 keys, sixteen 64-bit words - word e = 4 kt + r is the ballot of "keep" over the
+// wave for accumulator element (kt, r), i.e. bit 16 g + li <-> (query li of the block, key 16 kt + 4 g + r of the tile): the
+// compare result the forward select uses anyway, 128 bytes per wave and key tile (393 x 393 x 384 heads: 8.6 MB per call).  The
+// backward kernels never hash: dQ has the forward's lane <-> element mapping, loads the sixteen words with scalar loads and uses
+// each as the lane mask of its select; dK/dV holds one KEY per lane and four queries per accumulator block, so a lane fetches the
+// one word of its key (e = 4 kt(key) + r(key)) per 16-query block and tests bits 16 g(key) + 4 g + r.  In round 2 both backward
+// kernels re-hashed every element (+36 us of 170 at 393 x 393).
+//
 // Backward recomputes P from the saved log-sum-exp:
 //   dQ kernel  (per wave 16 NB queries, loops over key tiles):   dS^T = P^T o (dP^T - delta),  dQ^T = K^T . dS^T
 //   dKV kernel (per wave 16 NB keys, loops over query tiles):     dV^T = dO^T . P,  dK^T = Q^T . dS
@@ -45,7 +54,28 @@ struct AttnParams {
     float drop_scale;
     const uint64_t* seed_state;
     uint64_t stream_id;
+    uint64_t* keep;            // dropout lane masks [B*H][ceil(Sq/16)][ceil(Sk/64)][16] (written by forward, read by backward)
 };
+
+// first of the 16 mask words of (head bh, 16-query block qblk, 64-key tile ktile)
+__device__ __forceinline__ int64_t keep_word0(const AttnParams& P, int bh, int qblk, int ktile) {
+    const int nq16 = (P.Sq + 15) >> 4, nkt = (P.Sk + 63) >> 6;
+    return (((int64_t)bh * nq16 + qblk) * nkt + ktile) * 16;
+}
+// lane `lane` of (lo, hi) <- the two halves of the wave-uniform `mask` (v_writelane_b32; this compiler has no builtin for it).
+// `mask` is a compare result, i.e. an SGPR pair a VALU instruction has just written: v_writelane reads its scalar source too early
+// for that (measured: the words whose compare sat directly in front of the writelane came out stale), and the compiler's hazard
+// recogniser does not look into inline assembly - hence the wait states in front.  The lane is an immediate (one SGPR per instruction).
+__device__ __forceinline__ void write_lane_pair(uint64_t mask, int lane, int& lo, int& hi) {
+    asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi) : "s"((uint32_t)mask), "s"((uint32_t)(mask >> 32)), "i"(lane));
+}
+// x where the lane's bit of `mask` is set, else 0: the mask is an SGPR pair and goes straight into the select
+__device__ __forceinline__ float select_by_lane_mask(float x, uint64_t mask) {
+    float r;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+    return r;
+}
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -167,16 +197,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
                 alpha[n] = fast_exp2(m_run[n] - m_use);
                 moved = moved || (m_new != m_run[n]);
                 float rs = 0.f;
+                int keep_lo = 0, keep_hi = 0;              // lane e (< 16) collects mask word e = 4 kt + r
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float p = fast_exp2(s[n][kt][r] - m_use);
                         rs += p;
-                        if (DROP)
-                            p = dropout_keep_run(seed, (drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? p * P.drop_scale : 0.f;
+                        if (DROP) {
+                            const bool keep = dropout_keep_run(seed, (drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr);
+                            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);     // (the compare result itself: no extra instruction)
+                            write_lane_pair(m, 4 * kt + r, keep_lo, keep_hi);
+                            p = keep ? p * P.drop_scale : 0.f;
+                        }
                         s[n][kt][r] = p;
                     }
+                if (DROP) {
+                    const int qblk = (int)blockIdx.x * (4 * NB) + wave_u * NB + n;
+                    uint64_t* dst = P.keep + keep_word0(P, b * P.H + h, qblk, kb >> 6);
+                    if (lane < 16) dst[lane] = ((uint64_t)(uint32_t)keep_hi << 32) | (uint32_t)keep_lo;
+                }
                 rs = xrow_sum(rs);
                 l_run[n] = l_run[n] * alpha[n] + rs;
                 m_run[n] = m_new;
@@ -239,7 +279,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
     int qidx[NB], qrow[NB];
     Frag<T> qf[NB][2], df[NB][2];
     float dl[NB], lse2[NB];
-    uint64_t drop_row[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         qidx[n] = blockIdx.x * (64 * NB) + wave * (16 * NB) + 16 * n + li;
@@ -259,9 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
         if (g == 0 && qidx[n] < P.Sq) delta[stat] = d;
         dl[n] = d;
         lse2[n] = lse[stat] * LOG2E;
-        drop_row[n] = ((uint64_t)(b * P.H + h) * P.Sq + qrow[n]) * (uint64_t)((P.Sk + 1) & ~1);
     }
-    const uint64_t seed = DROP ? dropout_seed(P.seed_state, P.stream_id) : 0;
     const float c2 = P.scale * LOG2E;
     const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sq;       // wave-uniform, see the forward kernel
 
@@ -290,6 +327,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
         const float* ldsM = reinterpret_cast<const float*>(ldsK + 2 * TL::BYTES);
         if (kb + 64 < P.Sk) stage(cur ^ 1, kb + 64);
         if (active) {
+        // the forward's keep decisions of this (query block, key tile): sixteen lane masks per block, fetched by the scalar unit
+        // (wave-uniform address) while the matrix products below run; word e = 4 kt + r is the select mask of element (kt, r)
+        u32x8 km[NB][4];
+        if (DROP) {
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const uint64_t* mp = P.keep + keep_word0(P, b * P.H + h, (int)blockIdx.x * (4 * NB) + wave_u * NB + n, kb >> 6);
+                asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60"
+                             : "=&s"(km[n][0]), "=&s"(km[n][1]), "=&s"(km[n][2]), "=&s"(km[n][3]) : "s"(mp) : "memory");
+            }
+        }
         f32x4 s[NB][4], dp[NB][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -310,6 +358,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) mk[kt] = *reinterpret_cast<const f32x4*>(ldsM + 16 * kt + 4 * g) * LOG2E;
         }
+        if (DROP) {                                  // the scalar loads have landed (the wait also names the registers they wrote)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(km[n][0]), "+s"(km[n][1]), "+s"(km[n][2]), "+s"(km[n][3])::"memory");
+        }
         auto elems = [&](auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
 #pragma unroll
@@ -326,8 +379,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
                         float p = fast_exp2(t - lse2[n]);
                         if (TAIL) p = (kb + 16 * kt + 4 * g + r >= P.Sk) ? 0.f : p;
                         float dpe = dp[n][kt][r];
-                        if (DROP)
-                            dpe = dropout_keep_run(seed, (drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr) ? dpe * P.drop_scale : 0.f;
+                        if (DROP) {
+                            const u32x8 w8 = km[n][(4 * kt + r) >> 2];
+                            const uint64_t m = ((uint64_t)w8[2 * ((4 * kt + r) & 3) + 1] << 32) | w8[2 * ((4 * kt + r) & 3)];
+                            dpe = select_by_lane_mask(dpe * P.drop_scale, m);
+                        }
                         s[n][kt][r] = p * (dpe - dl[n]);
                     }
         };
@@ -393,11 +449,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
     const T* qbase = (const T*)P.q + (int64_t)b * P.q_bs + h * 64;
     const T* dbase = d_o + (int64_t)b * P.Sq * (P.H * 64) + h * 64;
     const int64_t stat0 = ((int64_t)b * P.H + h) * P.Sq;
-    const uint64_t seed = DROP ? dropout_seed(P.seed_state, P.stream_id) : 0;
-    const uint64_t drop_pitch = (uint64_t)((P.Sk + 1) & ~1);                       // even row pitch of the dropout counter
-    const bool odd_lane = (li & 1) != 0;
     const float c2 = P.scale * LOG2E;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // dropout: the forward's lane masks (see the head of the file).  This lane's key sits in tile krow >> 6 at (kt, g, r) =
+    // ((krow >> 4) & 3, (krow >> 2) & 3, krow & 3): it reads word e = 4 kt + r of every 16-query block and tests bits 16 g + ...
+    int64_t keep_base[NB];
+    int keep_shift[NB];
+    const int nq16 = (P.Sq + 15) >> 4;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        keep_base[n] = keep_word0(P, b * P.H + h, 0, krow[n] >> 6) + 4 * ((krow[n] >> 4) & 3) + (krow[n] & 3);
+        keep_shift[n] = 16 * ((krow[n] >> 2) & 3) + 4 * g;
+    }
+    const int64_t keep_qstep = (int64_t)((P.Sk + 63) >> 6) * 16;                  // words per 16-query block
     const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sk;       // wave-uniform, see the forward kernel
     const bool key_tail = (int)(blockIdx.x * (64 * NB) + (wave_u + 1) * (16 * NB)) > P.Sk;   // this wave holds keys past Sk
     auto stage = [&](int buf, int qb) {
@@ -428,11 +492,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
         const float* ldsDelta = ldsLse + 64;
         if (qb + 64 < P.Sq) stage(cur ^ 1, qb + 64);
         if (active) {
-        uint64_t drop_base[NB];                               // element index of (query qb + 4 g, key krow[n])
+        uint32_t kbits[NB][4];                                // keep bits of (queries 16 qt + 4 g + 0..3, this lane's key) in bits 0..3
         if (DROP) {
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-                drop_base[n] = ((uint64_t)(b * P.H + h) * P.Sq + (uint64_t)(qb + 4 * g)) * drop_pitch + (uint64_t)krow[n];
+#pragma unroll
+                for (int qt = 0; qt < 4; ++qt) {
+                    const int qblk = min((qb >> 4) + qt, nq16 - 1);                 // (blocks past Sq: don't-care, p is zeroed)
+                    const uint64_t w = P.keep[keep_base[n] + qblk * keep_qstep];
+                    kbits[n][qt] = (uint32_t)(w >> keep_shift[n]);
+                }
         }
         f32x4 s[NB][4], dp[NB][4];
 #pragma unroll
@@ -462,22 +531,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
             for (int n = 0; n < NB; ++n)
 #pragma unroll
                 for (int qt = 0; qt < 4; ++qt) {
-                    // dropout words of this lane's four (query, key) elements.  Keys 2j and 2j + 1 (lanes li = 2j, 2j + 1)
-                    // share the word of a query row (dropout_pair_word: one hash per element PAIR, pairs run along the keys,
-                    // row pitch even): the even lane hashes the rows r = 0, 1, the odd lane r = 2, 3, and they swap.  The row
-                    // offset (16 qt + r) * pitch is wave-uniform (scalar unit), so a word costs two 64-bit adds and the hash -
-                    // the first version paid a 64-bit vector multiply and a hash per ELEMENT, more than the tile's MFMAs.
-                    // (Queries past Sq / keys past Sk give don't-care words: p is zeroed below.)
-                    uint32_t wd[4] = {0, 0, 0, 0};
-                    if (DROP) {
-                        const uint64_t e0 = drop_base[n] + (uint64_t)(16 * qt) * drop_pitch + (uint64_t)(odd_lane ? 2 : 0) * drop_pitch;
-                        const uint32_t mine0 = dropout_pair_word(seed, e0 >> 1), mine1 = dropout_pair_word(seed, (e0 + drop_pitch) >> 1);
-                        const uint32_t other0 = __shfl_xor(mine0, 1, 64), other1 = __shfl_xor(mine1, 1, 64);
-                        wd[0] = odd_lane ? other0 : mine0;
-                        wd[1] = odd_lane ? other1 : mine1;
-                        wd[2] = odd_lane ? mine0 : other0;
-                        wd[3] = odd_lane ? mine1 : other1;
-                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int query = qb + 16 * qt + 4 * g + r;
@@ -491,7 +544,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                         float dpe = dp[n][qt][r];
                         float pd = p;
                         if (DROP) {
-                            const bool keep = dropout_keep_word(wd[r], krow[n] & 1, P.drop_thr);
+                            const bool keep = (kbits[n][qt] >> r) & 1u;
                             dpe = keep ? dpe * P.drop_scale : 0.f;
                             pd = keep ? p * P.drop_scale : 0.f;
                         }
@@ -551,6 +604,8 @@ static int attn_check(const AttnParams& P, int dtype, int mask_kind, float p_dro
     if (mask_kind < 0 || mask_kind > 2 || (mask_kind != SHG_MASK_NONE && !P.mask)) return fail_arg("attention: bad mask");
     if (p_drop < 0.f || p_drop >= 1.f) return fail_arg("attention: bad p_drop");
     if (p_drop > 0.f && !P.seed_state) return fail_arg("attention: dropout needs seed_state");
+    if (p_drop > 0.f && !P.keep) return fail_arg("attention: dropout needs the keep-mask buffer (shg_attention_keep_mask_bytes)");
+    if (P.keep && (reinterpret_cast<uintptr_t>(P.keep) & 127)) return fail_arg("attention: keep_mask must be 128-byte aligned");
     return 0;
 }
 
@@ -589,13 +644,18 @@ using namespace shg;
         else ATTN_DISPATCH_D(KERNEL, T, NB, false, LDS, __VA_ARGS__);                                                 \
     } while (0)
 
+extern "C" int64_t shg_attention_keep_mask_bytes(int B, int H, int Sq, int Sk) {
+    if (B < 1 || H < 1 || Sq < 1 || Sk < 1) return -1;
+    return (int64_t)B * H * ((Sq + 15) / 16) * ((Sk + 63) / 64) * 16 * 8;
+}
+
 extern "C" int shg_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B,
                                  int H, int Sq, int Sk, int64_t q_bstride, int64_t q_sstride, int64_t k_bstride,
                                  int64_t k_sstride, int64_t v_bstride, int64_t v_sstride, int mask_kind,
                                  const float* mask, float scale, float p_drop, const uint64_t* seed_state,
-                                 uint64_t stream_id, void* stream) {
+                                 uint64_t stream_id, uint64_t* keep_mask, void* stream) {
     AttnParams P{q, k, v, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride, mask, scale,
-                 dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id};
+                 dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id, keep_mask};
     if (int e = attn_check(P, dtype, mask_kind, p_drop)) return e;
     if (!o || !lse) return fail_arg("attention_fwd: null output");
     hipStream_t st = (hipStream_t)stream;
@@ -615,9 +675,10 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
                                  int64_t k_sstride, int64_t v_bstride, int64_t v_sstride, int64_t dq_bstride,
                                  int64_t dq_sstride, int64_t dk_bstride, int64_t dk_sstride, int64_t dv_bstride,
                                  int64_t dv_sstride, int mask_kind, const float* mask, float scale, float p_drop,
-                                 const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+                                 const uint64_t* seed_state, uint64_t stream_id, const uint64_t* keep_mask, void* stream) {
     AttnParams P{q, k, v, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride, mask, scale,
-                 dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id};
+                 dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id,
+                 const_cast<uint64_t*>(keep_mask)};
     if (int e = attn_check(P, dtype, mask_kind, p_drop)) return e;
     if (!o || !d_o || !lse || !delta || !dq || !dk || !dv) return fail_arg("attention_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;

@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
 
 #define SHG_WAVE 64
 
@@ -47,7 +48,10 @@ enum Tune {
                                // 2: no non-temporal accesses (3; isolated at 289 M parameters: 1.575 ms = 6.24 TB/s against
                                // 1.677 ms for the round-2 setting 1 / 16 384 blocks, tools/bertadam_bench.py) - "bertadam_mode"
     TUNE_BERTADAM_BLOCKS,      // grid cap (65536) - "bertadam_blocks"
-    TUNE_GEMM8_TILE_M,         // 0 auto (rounds x fill), 256 or 192: rows of the 8-phase tile - "gemm8_tile_m"
+    TUNE_GEMM8_TILE_M,         // rows of the 8-phase tile: 256 (default), 192, or 0 = the one with fewer rounds x work per tile.
+                               // Isolated, 0 wins on the 12 576-row problems with 768 / 1 536 columns (26.1 -> 23.0, 68.2 -> 58.6,
+                               // 45.5 -> 39.8 us); in the step, where the other streams' kernels use the CUs a 150-tile launch
+                               // leaves idle, the smaller tile's extra CU-time costs 0.4-2 % (three interleaved pairs) - "gemm8_tile_m"
     TUNE_ATTN_BWD_FUSED,       // 1: one backward kernel for dQ / dK / dV where available - "attn_bwd_fused"
     TUNE_EPILOGUE_SIDE,        // 1: GEMM row writers issue the loads of `C +=` / activation-backward forms up front - "epilogue_side"
     TUNE_COUNT

@@ -143,6 +143,7 @@ static int wgrad(const shg_run_t* R, const shg_linear_t& lin, const void* dy, in
 struct AttnSaved {
     void *qkv, *kv, *o, *z, *t;
     float *lse, *mean, *rstd;
+    uint64_t* keep;            // the forward's dropout lane masks (shg_attention_keep_mask_bytes)
     int64_t bytes;
 };
 static AttnSaved attn_saved(void* base, int mode, int dtype, int B, int Sq, int Sk, int heads) {
@@ -158,6 +159,7 @@ static AttnSaved attn_saved(void* base, int mode, int dtype, int B, int Sq, int 
     s.lse = (float*)c.take((int64_t)B * heads * Sq * 4);
     s.mean = (float*)c.take(rq * 4);
     s.rstd = (float*)c.take(rq * 4);
+    s.keep = (uint64_t*)c.take(shg_attention_keep_mask_bytes(B, heads, Sq, Sk));
     s.bytes = c.off;
     return s;
 }
@@ -243,7 +245,7 @@ static int attn_fwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int
         qb = (int64_t)Sq * H; qs = H; kb = (int64_t)Sk * 2 * H; ks = 2 * H;
     }
     CK(shg_attention_fwd(q, k, v, s.o, s.lse, dt, B, heads, Sq, Sk, qb, qs, kb, ks, kb, ks, L->mask_kind, L->mask, L->scale, pa,
-                         R->seed_state, sid, st));
+                         R->seed_state, sid, s.keep, st));
     CK(shg_gemm(s.o, L->o.w, s.t, nullptr, dt, dt, rq, H, H, H, H, H, 1, 1, 0, st));
     CK(shg_bias_act_drop_res_ln_fwd_pos(s.t, L->o.bias, x, L->ln.gamma, L->ln.beta, y, s.z, s.mean, s.rstd, pos, y_pos, dt, rq, (int)H,
                                         SHG_ACT_NONE, L->ln.eps, po, R->seed_state, sid + 1, st));
@@ -273,7 +275,7 @@ static int attn_bwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int
         const int64_t qb = (int64_t)Sq * 3 * H, qs = 3 * H;
         CK(shg_attention_bwd(q, q + H * es, q + 2 * H * es, s.o, w.d_o, s.lse, w.delta, dq, dq + H * es, dq + 2 * H * es, dt, B, heads,
                              Sq, Sk, qb, qs, qb, qs, qb, qs, qb, qs, qb, qs, qb, qs, L->mask_kind, L->mask, L->scale, pa,
-                             R->seed_state, sid, st));
+                             R->seed_state, sid, s.keep, st));
         if (mode == SHG_ATTN_SELF) {
             CK(wgrad(R, L->a, dq, 3 * H, x, H, rq, 3 * H, H, true));
             if (dx) CK(shg_gemm(dq, L->a.w, dx, nullptr, dt, dt, rq, H, 3 * H, 3 * H, H, H, 1, 0, 1, st));
@@ -289,7 +291,7 @@ static int attn_bwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int
         char* dk = (char*)w.dkv;
         const int64_t qb = (int64_t)Sq * H, qs = H, kb = (int64_t)Sk * 2 * H, ks = 2 * H;
         CK(shg_attention_bwd(s.qkv, k, k + H * es, s.o, w.d_o, s.lse, w.delta, w.dqkv, dk, dk + H * es, dt, B, heads, Sq, Sk, qb, qs,
-                             kb, ks, kb, ks, qb, qs, kb, ks, kb, ks, L->mask_kind, L->mask, L->scale, pa, R->seed_state, sid, st));
+                             kb, ks, kb, ks, qb, qs, kb, ks, kb, ks, L->mask_kind, L->mask, L->scale, pa, R->seed_state, sid, s.keep, st));
         CK(wgrad(R, L->a, w.dqkv, H, mode == SHG_ATTN_DEC_CROSS ? xpos : x, H, rq, H, H, true));
         CK(wgrad(R, L->b, w.dkv, 2 * H, mem, H, rk, 2 * H, H, true));
         if (mode == SHG_ATTN_CROSS) {

@@ -1329,14 +1329,19 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const f32x4* slot = reinterpret_cast<const f32x4*>(sk.ws + (size_t)sl * STREAMK_SLOT) + tid;
+            // (eight vectors at a time with a scheduling fence between the groups: left to itself the scheduler issues all 32
+            //  loads first - 128 more live registers beside the 128 accumulators - and everything else the epilogue needs is
+            //  spilled around the main loop)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 2; ++b) {
 #pragma unroll
                     for (int i = 0; i < NI; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc[a][b][i][j] += slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
     }
 
@@ -1507,7 +1512,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
     if constexpr (std::is_same<SrcA, PlainSrc<bf16_t, true>>::value && ALLOW_SK == 0) {
         const int64_t gm192 = (M + 191) / 192, tiles192 = gm192 * gn, want = tuning(TUNE_GEMM8_TILE_M);
         const int64_t cost256 = 4 * ((tiles + 255) / 256), cost192 = 3 * ((tiles192 + 255) / 256);
-        if (split == 1 && !ep.atomic && tiles192 <= 0x7fffffff && (want == 192 || (want == 0 && cost192 < cost256))) {
+        if (split == 1 && !ep.atomic && tiles192 <= 0x7fffffff && (want == 192 || (want == 0 && cost192 < cost256))) {   // (default: 256)
             auto kern = gemm8_kernel<TC, SrcA, SrcB, false, 192>;
             static std::atomic<uint64_t> raised192{0};
             raise_lds_limit(raised192, reinterpret_cast<const void*>(kern), (int)lds);

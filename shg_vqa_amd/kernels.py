@@ -289,8 +289,18 @@ def _mask_args(mask_kind, mask, b, sq, sk):
     return mask
 
 
-def attention_fwd(q, k, v, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p_drop=0.0, seed_state=None, stream_id=0):
-    """q [B,Sq,H*64], k/v [B,Sk,H*64] (views into fused projections allowed) -> (o [B,Sq,H*64], lse [B,H,Sq])."""
+def attention_keep_mask(b, heads, sq, sk, device):
+    """Buffer for the forward's dropout keep decisions (lane masks, csrc/attention.hip): int64 words, 128-byte aligned."""
+    n = _lib.lib().shg_attention_keep_mask_bytes(b, heads, sq, sk) // 8
+    buf = torch.empty(n + 16, dtype=torch.int64, device=device)
+    off = (-buf.data_ptr() // 8) % 16
+    return buf[off:off + n]
+
+
+def attention_fwd(q, k, v, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p_drop=0.0, seed_state=None, stream_id=0, keep_mask=None):
+    """q [B,Sq,H*64], k/v [B,Sk,H*64] (views into fused projections allowed) -> (o [B,Sq,H*64], lse [B,H,Sq]).
+    With dropout the keep decisions are written to `keep_mask` (attention_keep_mask(...)); when none is passed one is allocated
+    and travels with the returned lse tensor (attribute _shg_keep), where attention_bwd finds it."""
     _dev(q, k, v, mask, seed_state)
     b, sq, qb, qs = _attn_view(q, "q")
     b2, sk, kb, ks = _attn_view(k, "k")
@@ -302,15 +312,26 @@ def attention_fwd(q, k, v, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p
     _need(p_drop == 0.0 or seed_state is not None, "dropout needs seed_state")
     o = torch.empty((b, sq, heads * 64), dtype=q.dtype, device=q.device)
     lse = torch.empty((b, heads, sq), dtype=torch.float32, device=q.device)
+    if p_drop > 0.0 and keep_mask is None:
+        keep_mask = attention_keep_mask(b, heads, sq, sk, q.device)
+    if keep_mask is not None:
+        _dev(keep_mask)
+        _need(keep_mask.dtype == torch.int64 and keep_mask.is_contiguous()
+              and keep_mask.numel() * 8 >= _lib.lib().shg_attention_keep_mask_bytes(b, heads, sq, sk), "keep_mask too small")
+        lse._shg_keep = keep_mask
     _lib.call("shg_attention_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), _dt(q), b,
               heads, sq, sk, qb, qs, kb, ks, vb, vs, mask_kind, _p(mask), float(scale), float(p_drop), _p(seed_state),
-              int(stream_id), _stream())
+              int(stream_id), _p(keep_mask), _stream())
     return o, lse
 
 
 def attention_bwd(q, k, v, o, d_o, lse, dq, dk, dv, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p_drop=0.0,
-                  seed_state=None, stream_id=0):
-    """Writes dq/dk/dv (views with the same layout rules as q/k/v)."""
+                  seed_state=None, stream_id=0, keep_mask=None):
+    """Writes dq/dk/dv (views with the same layout rules as q/k/v).  With dropout: keep_mask = the buffer the forward call
+    filled (default: the one attention_fwd attached to `lse`)."""
+    if p_drop > 0.0 and keep_mask is None:
+        keep_mask = getattr(lse, "_shg_keep", None)
+        _need(keep_mask is not None, "attention_bwd with dropout needs the forward call's keep_mask")
     _dev(q, k, v, o, d_o, lse, dq, dk, dv, mask, seed_state)
     b, sq, qb, qs = _attn_view(q, "q")
     _, sk, kb, ks = _attn_view(k, "k")
@@ -329,7 +350,7 @@ def attention_bwd(q, k, v, o, d_o, lse, dq, dk, dv, heads, mask_kind=MASK_NONE, 
     _lib.call("shg_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
               delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _dt(q), b, heads, sq, sk, qb, qs, kb, ks,
               vb, vs, dqb, dqs, dkb, dks, dvb, dvs, mask_kind, _p(mask), float(scale), float(p_drop), _p(seed_state),
-              int(stream_id), _stream())
+              int(stream_id), _p(keep_mask), _stream())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -341,6 +341,7 @@ class _Attention(torch.autograd.Function):
     def forward(ctx, q, k, v, heads, mask_kind, mask, scale, p):
         p, seed, sid = _drop_args(p)
         o, lse = K.attention_fwd(q, k, v, heads, mask_kind, mask, scale, p, seed, sid)
+        ctx.keep = getattr(lse, "_shg_keep", None)          # dropout lane masks written by the forward kernel
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.cfg = (heads, mask_kind, mask, scale, p, seed, sid)
         return o
@@ -352,7 +353,7 @@ class _Attention(torch.autograd.Function):
         dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
         dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
         dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
-        K.attention_bwd(q, k, v, o, d_o.contiguous(), lse, dq, dk, dv, heads, mask_kind, mask, scale, p, seed, sid)
+        K.attention_bwd(q, k, v, o, d_o.contiguous(), lse, dq, dk, dv, heads, mask_kind, mask, scale, p, seed, sid, keep_mask=ctx.keep)
         return dq, dk, dv, None, None, None, None, None
 
 
@@ -822,6 +823,7 @@ class _SelfAttnQKV(torch.autograd.Function):
         K.gemm(x2, E.operand(w_qkv), qkv, b_qkv._shg_store.view(-1), True, True)
         q3 = qkv.view(B, S, 3 * H)
         o, lse = K.attention_fwd(q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:], heads, mask_kind, mask, scale, p, seed, sid)
+        ctx.keep = getattr(lse, "_shg_keep", None)          # dropout lane masks written by the forward kernel
         ctx.save_for_backward(x2, qkv, o, lse)
         ctx.cfg = (w_qkv, b_qkv, heads, mask_kind, mask, scale, p, seed, sid, (B, S, H))
         return o
@@ -835,7 +837,7 @@ class _SelfAttnQKV(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         d3 = dqkv.view(B, S, 3 * H)
         K.attention_bwd(q3[:, :, :H], q3[:, :, H:2 * H], q3[:, :, 2 * H:], o, d_o.contiguous(), lse,
-                        d3[:, :, :H], d3[:, :, H:2 * H], d3[:, :, 2 * H:], heads, mask_kind, mask, scale, p, seed, sid)
+                        d3[:, :, :H], d3[:, :, H:2 * H], d3[:, :, 2 * H:], heads, mask_kind, mask, scale, p, seed, sid, keep_mask=ctx.keep)
         _wgrad(dqkv, x2, w_qkv, b_qkv)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -864,6 +866,7 @@ class _CrossAttnQKV(torch.autograd.Function):
         K.gemm(c2, E.operand(w_kv), kv, b_kv._shg_store.view(-1), True, True)
         kv3 = kv.view(B, Sk, 2 * H)
         o, lse = K.attention_fwd(q.view(B, Sq, H), kv3[:, :, :H], kv3[:, :, H:], heads, mask_kind, mask, scale, p, seed, sid)
+        ctx.keep = getattr(lse, "_shg_keep", None)          # dropout lane masks written by the forward kernel
         ctx.save_for_backward(h2, c2, q, kv, o, lse)
         ctx.cfg = (w_q, b_q, w_kv, b_kv, heads, mask_kind, mask, scale, p, seed, sid, (B, Sq, Sk, H))
         return o
@@ -878,7 +881,7 @@ class _CrossAttnQKV(torch.autograd.Function):
         dkv = torch.empty_like(kv)
         dkv3 = dkv.view(B, Sk, 2 * H)
         K.attention_bwd(q.view(B, Sq, H), kv3[:, :, :H], kv3[:, :, H:], o, d_o.contiguous(), lse, dq.view(B, Sq, H),
-                        dkv3[:, :, :H], dkv3[:, :, H:], heads, mask_kind, mask, scale, p, seed, sid)
+                        dkv3[:, :, :H], dkv3[:, :, H:], heads, mask_kind, mask, scale, p, seed, sid, keep_mask=ctx.keep)
         _wgrad(dq, h2, w_q, b_q)
         _wgrad(dkv, c2, w_kv, b_kv)
         dh = dc = None

@@ -23,8 +23,8 @@ def timeit(fn, n=20):
 
 
 which = sys.argv[1:] or ["attn", "ln", "wgrad"]
-if "attn" in which:
-    for (B, H, Sq, Sk, mk, p) in [(32, 12, 393, 393, K.MASK_KEY, 0.0), (32, 12, 393, 393, K.MASK_KEY, 0.1), (32, 12, 128, 128, K.MASK_FULL, 0.15),
+if "attn" in which or "attn393" in which:
+    for (B, H, Sq, Sk, mk, p) in [(32, 12, 393, 393, K.MASK_KEY, 0.1)] if "attn393" in which else [(32, 12, 393, 393, K.MASK_KEY, 0.0), (32, 12, 393, 393, K.MASK_KEY, 0.1), (32, 12, 128, 128, K.MASK_FULL, 0.15),
                                   (32, 12, 128, 393, K.MASK_NONE, 0.15), (32, 12, 48, 393, K.MASK_NONE, 0.15), (32, 12, 40, 40, K.MASK_KEY, 0.1),
                                   (32, 12, 177, 40, K.MASK_KEY, 0.1), (32, 12, 40, 177, K.MASK_NONE, 0.1)]:
         qkv = torch.randn(B, Sq, 3 * H * 64, device=dev).to(bf)
