@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
         const T* qptr = (const T*)P.q + (int64_t)b * P.q_bs + (int64_t)qrow[n] * P.q_ss + h * 64;
         qf[n][0] = glb_row_frag(qptr, 0, g);
         qf[n][1] = glb_row_frag(qptr, 32, g);
-        drop_row[n] = ((uint64_t)(b * P.H + h) * P.Sq + qrow[n]) * (uint64_t)((P.Sk + 1) & ~1);   // even row pitch
+        drop_row[n] = ((uint64_t)(b * P.H + h) * P.Sq + qrow[n]) * (uint64_t)((P.Sk + 3) & ~3);   // row pitch: a multiple of 4 (quads)
     }
     const uint64_t seed = DROP ? dropout_seed(P.seed_state, P.stream_id) : 0;
     const float c2 = P.scale * LOG2E;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
                         float p = fast_exp2(s[n][kt][r] - m_use);
                         rs += p;
                         if (DROP) {
-                            const bool keep = dropout_keep_run(seed, (drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g)) >> 1, r, P.drop_thr);
+                            const bool keep = dropout_keep_run(seed, drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g), r, P.drop_thr);
                             const uint64_t m = __builtin_amdgcn_ballot_w64(keep);     // (the compare result itself: no extra instruction)
                             write_lane_pair(m, 4 * kt + r, keep_lo, keep_hi);
                             p = keep ? p * P.drop_scale : 0.f;

@@ -158,11 +158,15 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 // ------------------------------------------------------------------ counter-based dropout RNG
-// keep(element) is a pure function of (seed, stream, element index) so that backward kernels regenerate
-// the forward mask.  One 32-bit hash serves the PAIR of elements (2p, 2p+1): 16 random bits each, compared
-// with the upper 16 bits of the threshold (p is resolved to 1/65536).  All arithmetic is 32-bit: the former
-// 64-bit splitmix cost ~15 integer multiplies per element, which made the dropout the most expensive part of
-// the attention and LayerNorm kernels.  (Integer hash: the "lowbias32" constants of Wellons' hash prospector.)
+// keep(element) is a pure function of (seed, stream, element index), so a backward kernel can regenerate the forward mask (the
+// attention kernels store theirs instead, attention.hip).  One hash serves the aligned QUAD of elements 4q .. 4q+3: 64 random
+// bits, 16 per element, compared with the upper 16 bits of the threshold (p is resolved to 1/65536).  The hash is three
+// multiply-folds: a 32 x 32 -> 64-bit product (one v_mad_u64_u32, measured 5.4 cycles per wave against 3.4 for an xor and 5.1
+// for a 32-bit multiply, tools/native/valu_rates.hip) whose halves are xor-ed - every output bit then depends on every input
+// bit - once on the counter and twice, with different constants, on the result: 3 products + ~6 single-issue instructions per
+// quad against two rounds of xorshift-multiply (12 instructions) per PAIR in rounds 1-2.  Statistics of the four fields
+// (tools/hash_quality.py: rate, chi-square of the 16-bit fields, correlation within a quad, serial correlation at lags 1, 2, 3,
+// one row, one head, 2^16, 2^20, and between consecutive seeds) are those of the old hash.
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352dU;
@@ -171,25 +175,27 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
-// random word of element pair `pair` (= element index >> 1); `seed` comes from dropout_seed().
-// 32-bit integer multiplies are quarter-rate instructions (16 cycles per wave, as much as the exponential of a softmax
-// element), so the counter goes into the hash by addition only: the two multiplies left are those of hash32 itself, which
-// avalanches consecutive counters on its own.  (The attention kernels spend as long on these masks as on the softmax.)
-__device__ __forceinline__ uint32_t dropout_pair_word(uint64_t seed, uint64_t pair) {
-    const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
-    return hash32(lo + (uint32_t)seed + ((hi << 16) | (hi >> 16))) ^ (uint32_t)(seed >> 32);
+__device__ __forceinline__ uint32_t mulfold(uint32_t x, uint32_t c) {
+    const uint64_t p = (uint64_t)x * c;
+    return (uint32_t)p ^ (uint32_t)(p >> 32);
 }
-__device__ __forceinline__ bool dropout_keep_word(uint32_t word, int odd, uint32_t threshold) {
-    return ((word >> (odd ? 16 : 0)) & 0xFFFFu) >= (threshold >> 16);
+struct DropQuad { uint32_t w0, w1; };                // elements 0, 1 in the halves of w0, elements 2, 3 in the halves of w1
+__device__ __forceinline__ DropQuad dropout_quad_words(uint64_t seed, uint64_t quad) {
+    const uint32_t lo = (uint32_t)quad, hi = (uint32_t)(quad >> 32);
+    const uint32_t y = mulfold(lo + (uint32_t)seed + ((hi << 16) | (hi >> 16)), 0x9E3779B1u) ^ (uint32_t)(seed >> 32);
+    return DropQuad{mulfold(y, 0x85EBCA77u), mulfold(y, 0xC2B2AE3Du)};
+}
+__device__ __forceinline__ bool dropout_keep_field(const DropQuad& q, int k, uint32_t threshold) {
+    return ((((k & 2) ? q.w1 : q.w0) >> ((k & 1) ? 16 : 0)) & 0xFFFFu) >= (threshold >> 16);
 }
 // threshold = (uint32_t)(p * 2^32); keep iff the element's 16 random bits >= threshold >> 16
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t threshold) {
-    return dropout_keep_word(dropout_pair_word(seed, idx >> 1), (int)(idx & 1), threshold);
+    return dropout_keep_field(dropout_quad_words(seed, idx >> 2), (int)(idx & 3), threshold);
 }
-// element j of a run that starts at the EVEN index 2 * pair_base (j a compile-time constant after unrolling:
-// the two elements of a pair then share one hash)
-__device__ __forceinline__ bool dropout_keep_run(uint64_t seed, uint64_t pair_base, int j, uint32_t threshold) {
-    return dropout_keep_word(dropout_pair_word(seed, pair_base + (uint64_t)(j >> 1)), j & 1, threshold);
+// element j of a run that starts at the element index `base`, a multiple of 4 (j a compile-time constant after unrolling: the
+// four elements of a quad then share one hash)
+__device__ __forceinline__ bool dropout_keep_run(uint64_t seed, uint64_t base, int j, uint32_t threshold) {
+    return dropout_keep_field(dropout_quad_words(seed, (base >> 2) + (uint64_t)(j >> 2)), j & 3, threshold);
 }
 __host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) {
     double t = (double)p * 4294967296.0;

@@ -456,7 +456,7 @@ template <> struct RowWriter<bf16_t> {
                 bf16x8 o;
                 if (drop) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
+                    for (int r = 0; r < 8; ++r) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n), r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -477,7 +477,7 @@ template <> struct RowWriter<bf16_t> {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
                         const float a = act_ct<ACT, true>(u[r]);
-                        o[r] = (bf16_t)(dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? a * ep.drop_scale : 0.f);
+                        o[r] = (bf16_t)(dropout_keep_run(dseed, (uint64_t)(m * N + n), r, ep.drop_thr) ? a * ep.drop_scale : 0.f);
                     }
                 } else {
 #pragma unroll
@@ -568,7 +568,7 @@ template <> struct RowWriter<float> {
                 const f32x4 gp = *reinterpret_cast<const f32x4*>(ep.gpre + m * N + n);
                 if (drop) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
+                    for (int r = 0; r < 4; ++r) u[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n), r, ep.drop_thr) ? u[r] * ep.drop_scale : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -583,7 +583,7 @@ template <> struct RowWriter<float> {
                 if (drop) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        o[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n) >> 1, r, ep.drop_thr) ? o[r] * ep.drop_scale : 0.f;
+                        o[r] = dropout_keep_run(dseed, (uint64_t)(m * N + n), r, ep.drop_thr) ? o[r] * ep.drop_scale : 0.f;
                 }
                 if (ep.accumulate) o += *reinterpret_cast<const f32x4*>(dst);
                 *reinterpret_cast<f32x4*>(dst) = o;
@@ -1065,7 +1065,9 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NTHR = 512;
     constexpr bool AK = SrcA::KMAJOR, BKM = SrcB::KMAJOR;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    int tid_ = threadIdx.x;
+    if constexpr (SK) asm volatile("" : "+v"(tid_));   // (per segment: nothing derived from the thread id is carried from one segment into the next)
+    const int tid = tid_, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wr = wave_u >> 2, wc = wave_u & 3;
     // K % 64 != 0 is supported for the form with BOTH operands contraction-strided plain matrices (weight gradients over a
@@ -1291,6 +1293,13 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
 #undef SHG_G8_RB
     if (wr == 0) __builtin_amdgcn_s_barrier();      // re-align the wave groups
     __syncthreads();
+    // Everything below addresses memory through these re-derived lane coordinates.  In the stream-K kernel the body sits in a
+    // loop over segments: values that only depend on the thread id (staging pointers, slot addresses, row-writer columns) are
+    // loop-invariant there, get hoisted in front of the FIRST segment and then live - or rather: are spilled - across every main
+    // loop.  Laundering the thread id here pins their computation behind the main loop.
+    int tid2 = tid;
+    if constexpr (SK) asm volatile("" : "+v"(tid2));
+    const int wave2 = tid2 >> 6, lane2 = tid2 & 63, g2 = lane2 >> 4, li2 = lane2 & 15;
 
     if constexpr (SK) {
         int s_ = seg;
@@ -1298,7 +1307,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
         if (!d.owner) {
             // tail segment: publish the raw accumulators (register r of thread t at float4 index r * 512 + t)
-            f32x4* slot = reinterpret_cast<f32x4*>(sk.ws + (size_t)d.slot * STREAMK_SLOT) + tid;
+            f32x4* slot = reinterpret_cast<f32x4*>(sk.ws + (size_t)d.slot * STREAMK_SLOT) + tid2;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1309,7 +1318,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
                         for (int j = 0; j < 2; ++j) slot[(((a * 2 + b) * 4 + i) * 2 + j) * NTHR] = acc[a][b][i][j];
             __threadfence();
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(sk.flags + d.slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid2 == 0) __hip_atomic_store(sk.flags + d.slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();                             // the accumulators' LDS staging area is the next segment's operand buffer
             return true;
         }
@@ -1320,7 +1329,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         // starve them.  tests/test_host_cpu.py checks on the plan that every publisher has a lower block index than its owner.
         for (int part = 0; part < d.parts; ++part) {
             const int sl = 2 * d.tile + part;
-            if (tid == 0) {
+            if (tid2 == 0) {
                 // (relaxed polls: an ACQUIRE load at agent scope invalidates the XCD's L2 on EVERY poll - under the tails that are
                 //  still streaming their operand panels through it; the one acquire fence below orders the reads of the slot)
                 while (__hip_atomic_load(sk.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
@@ -1328,7 +1337,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
             }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const f32x4* slot = reinterpret_cast<const f32x4*>(sk.ws + (size_t)sl * STREAMK_SLOT) + tid;
+            const f32x4* slot = reinterpret_cast<const f32x4*>(sk.ws + (size_t)sl * STREAMK_SLOT) + tid2;
             // (eight vectors at a time with a scheduling fence between the groups: left to itself the scheduler issues all 32
             //  loads first - 128 more live registers beside the 128 accumulators - and everything else the epilogue needs is
             //  spilled around the main loop)
@@ -1345,17 +1354,17 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         }
     }
 
-    // epilogue: per A half, a wave holds 64 rows x (32 + 32) columns, the second 32 columns 128 further right in C.  Two
+    // epilogue: per A half, a wave2 holds 64 rows x (32 + 32) columns, the second 32 columns 128 further right in C.  Two
     // neighbouring waves (wc = 2q, 2q + 1) therefore own the two halves of the same 64-column blocks: they stage both blocks
     // together (one 64 x 64 fp32 piece each) and each writes ONE of them, in whole 128-byte rows of bf16 (256-byte of fp32) -
     // writing the 32-column halves separately made every store a partial L2 line.
-    float* stg0 = reinterpret_cast<float*>(smem) + (wave & ~1) * (64 * STG_LD);     // the pair's left block (columns 64 q ..)
+    float* stg0 = reinterpret_cast<float*>(smem) + (wave2 & ~1) * (64 * STG_LD);     // the pair's left block (columns 64 q ..)
     float* stg1 = stg0 + 64 * STG_LD;                                               // its right block (columns 128 + 64 q ..)
     const int half = wc & 1;
     float csum_carry[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bias-gradient sums of both A halves (same columns)
     // (the A half is a compile-time constant of the lambda: as a `#pragma unroll` loop the compiler stops unrolling it once the
     //  row writer grows past its size threshold, indexes acc[a] dynamically and moves the whole accumulator array into scratch -
-    //  528 bytes per lane, zero-filled before the main loop)
+    //  528 bytes per lane2, zero-filled before the main loop)
     auto epilogue_half = [&](auto a_c) {
         constexpr int a = decltype(a_c)::value;
         if (a) __syncthreads();
@@ -1365,13 +1374,13 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li) * STG_LD + 32 * half + 16 * j + 4 * g) = acc[a][b][i][j];
+                    *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li2) * STG_LD + 32 * half + 16 * j + 4 * g2) = acc[a][b][i][j];
         __syncthreads();
         RowWriter<TC>::template run<!SK, WROWS>(half ? stg1 : stg0, ep, m0 + HALF * a + WROWS * wr, n0 + 128 * half + 64 * (wc >> 1), M, N,
-                                                lane, 0, csum_carry);
+                                                lane2, 0, csum_carry);
     };
     if constexpr (SK) {                              // (the stream-K body keeps the loop form: its register allocation is at the limit
-#pragma unroll                                       //  and this form spills least - 168 against 244 bytes per lane)
+#pragma unroll                                       //  and this form spills least - 168 against 244 bytes per lane2)
         for (int a = 0; a < 2; ++a) {
             if (a) __syncthreads();
 #pragma unroll
@@ -1380,16 +1389,16 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li) * STG_LD + 32 * half + 16 * j + 4 * g) = acc[a][b][i][j];
+                        *reinterpret_cast<f32x4*>((b ? stg1 : stg0) + (16 * i + li2) * STG_LD + 32 * half + 16 * j + 4 * g2) = acc[a][b][i][j];
             __syncthreads();
-            RowWriter<TC>::template run<false>(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane, 0,
+            RowWriter<TC>::template run<false>(half ? stg1 : stg0, ep, m0 + 128 * a + 64 * wr, n0 + 128 * half + 64 * (wc >> 1), M, N, lane2, 0,
                                                csum_carry);
         }
     } else {
         epilogue_half(std::integral_constant<int, 0>{});
         epilogue_half(std::integral_constant<int, 1>{});
     }
-    if (ep.csum) RowWriter<TC>::flush_csum(csum_carry, ep, n0 + 128 * half + 64 * (wc >> 1), N, lane);
+    if (ep.csum) RowWriter<TC>::flush_csum(csum_carry, ep, n0 + 128 * half + 64 * (wc >> 1), N, lane2);
     if constexpr (SK) __syncthreads();               // the staging area is the next segment's first operand buffer
     }
     return true;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             for (int j = 0; j < V; ++j) {
                 float u = xv.get(j) + bv[j];
                 u = act_fwd<ACT, (sizeof(T) == 2)>(u);
-                if (DROP) u = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? u * drop_scale : 0.f;
+                if (DROP) u = dropout_keep_run(seed, (uint64_t)off, j, drop_thr) ? u * drop_scale : 0.f;
                 if (residual) u += rv.get(j);
                 zv[i][j] = u;
                 sum += u;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     const float dz = rs * (gyv[i][j] - s1 - xh[i][j] * s2);
                     dzv.set(j, dz);
                     float d = dz;
-                    if (DROP) d = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? d * drop_scale : 0.f;
+                    if (DROP) d = dropout_keep_run(seed, (uint64_t)off, j, drop_thr) ? d * drop_scale : 0.f;
                     if (ACT != SHG_ACT_NONE) d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + bsv[j]);
                     dxv.set(j, d);
                     abias[i][j] += to_f32(from_f32<T>(d));
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float u = act_fwd<ACT, (sizeof(T) == 2)>(xv.get(j) + bv[j]);
-            if (DROP) u = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? u * drop_scale : 0.f;
+            if (DROP) u = dropout_keep_run(seed, (uint64_t)off, j, drop_thr) ? u * drop_scale : 0.f;
             yv.set(j, u);
         }
         store16(y + off, yv);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     float d = gv.get(j);
-                    if (DROP) d = dropout_keep_run(seed, (uint64_t)off >> 1, j, drop_thr) ? d * drop_scale : 0.f;
+                    if (DROP) d = dropout_keep_run(seed, (uint64_t)off, j, drop_thr) ? d * drop_scale : 0.f;
                     d *= act_grad<ACT, (sizeof(T) == 2)>(xv.get(j) + bsv[i][j]);
                     dv.set(j, d);
                     ab[i][j] += to_f32(from_f32<T>(d));
