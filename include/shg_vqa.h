@@ -49,7 +49,7 @@ const char* shg_last_error_string(void);
  * table with its measured-best default (csrc/common.h `enum Tune`, csrc/api.hip): "attn_nb", "attn_nb_dq", "attn_nb_dkv",
  * "tile_order", "gemm4_max_tiles", "streamk_sigma", "streamk", "gemm8", "gemm8_min_tiles", "splitk_target", "splitk_min_steps",
  * "large_min_k", "wgrad_group", "conv_wgrad_remainder", "bertadam_mode", "bertadam_blocks", "gemm8_tile_m", "attn_bwd_fused",
- * "epilogue_side".
+ * "epilogue_side", "repeat_family" (diagnostic: launches of a kernel family are issued twice, tools/family_cost.py).
  * A binding sets them once (the Python host maps SHG_<NAME> environment variables onto them at load time); host-side only, takes
  * effect at the next launch.  shg_set_tuning: 0 or SHG_ERR_INVALID (unknown name); shg_get_tuning: value or INT64_MIN;
  * shg_tuning_name(i): name of entry i, NULL past the end.  (The reference has no counterpart: its knobs are argparse flags,

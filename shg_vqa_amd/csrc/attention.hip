@@ -62,13 +62,20 @@ __device__ __forceinline__ int64_t keep_word0(const AttnParams& P, int bh, int q
     const int nq16 = (P.Sq + 15) >> 4, nkt = (P.Sk + 63) >> 6;
     return (((int64_t)bh * nq16 + qblk) * nkt + ktile) * 16;
 }
-// lane `lane` of (lo, hi) <- the two halves of the wave-uniform `mask` (v_writelane_b32; this compiler has no builtin for it).
-// `mask` is a compare result, i.e. an SGPR pair a VALU instruction has just written: v_writelane reads its scalar source too early
-// for that (measured: the words whose compare sat directly in front of the writelane came out stale), and the compiler's hazard
-// recogniser does not look into inline assembly - hence the wait states in front.  The lane is an immediate (one SGPR per instruction).
-__device__ __forceinline__ void write_lane_pair(uint64_t mask, int lane, int& lo, int& hi) {
-    asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-        : "+v"(lo), "+v"(hi) : "s"((uint32_t)mask), "s"((uint32_t)(mask >> 32)), "i"(lane));
+// The sixteen mask words of a (query block, key tile) go to memory through the SCALAR unit (s_store_dwordx2: they are compare
+// results, i.e. SGPR pairs already - moving them into a vector register first cost 32 v_writelane per key tile in a kernel that is
+// bound by its vector instructions).  The masks were written by VALU compares: the scalar memory instruction must not read them in
+// the next few cycles, and the compiler's hazard recogniser does not look into inline assembly - hence the s_nop in front (the
+// first version of this path moved the words with v_writelane directly behind the compare and stored stale ones).  The scalar
+// data cache is written back at the end of the kernel (attn_fwd_kernel: s_dcache_wb).
+__device__ __forceinline__ void store_keep_masks(uint64_t* dst, const uint64_t (&m)[16]) {
+    asm volatile("s_nop 4\n\t"
+                 "s_store_dwordx2 %1, %0, 0x0\n\ts_store_dwordx2 %2, %0, 0x8\n\ts_store_dwordx2 %3, %0, 0x10\n\ts_store_dwordx2 %4, %0, 0x18\n\t"
+                 "s_store_dwordx2 %5, %0, 0x20\n\ts_store_dwordx2 %6, %0, 0x28\n\ts_store_dwordx2 %7, %0, 0x30\n\ts_store_dwordx2 %8, %0, 0x38\n\t"
+                 "s_store_dwordx2 %9, %0, 0x40\n\ts_store_dwordx2 %10, %0, 0x48\n\ts_store_dwordx2 %11, %0, 0x50\n\ts_store_dwordx2 %12, %0, 0x58\n\t"
+                 "s_store_dwordx2 %13, %0, 0x60\n\ts_store_dwordx2 %14, %0, 0x68\n\ts_store_dwordx2 %15, %0, 0x70\n\ts_store_dwordx2 %16, %0, 0x78"
+                 :: "s"(dst), "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]), "s"(m[8]), "s"(m[9]),
+                    "s"(m[10]), "s"(m[11]), "s"(m[12]), "s"(m[13]), "s"(m[14]), "s"(m[15]) : "memory");
 }
 // x where the lane's bit of `mask` is set, else 0: the mask is an SGPR pair and goes straight into the select
 __device__ __forceinline__ float select_by_lane_mask(float x, uint64_t mask) {
@@ -108,11 +115,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
     const T* kbase = (const T*)P.k + (int64_t)b * P.k_bs + h * 64;
     const T* vbase = (const T*)P.v + (int64_t)b * P.v_bs + h * 64;
     const float* mrow = (MASK == SHG_MASK_KEY) ? P.mask + (int64_t)b * P.Sk : nullptr;
+    const TileLaneOffsets<T> koff = tile_lane_offsets<T>(P.k_ss, tid), voff = tile_lane_offsets<T>(P.v_ss, tid);
     auto stage = [&](int buf, int kb) {
         char* base = smem + buf * STG;
         const int valid = min(64, P.Sk - kb);
-        load_tile64_async<T>(base, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
-        load_tile64_async<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
+        if (valid == 64) {                          // whole tile: scalar base + the lane offsets computed once
+            load_tile64_async_full<T>(base, kbase + (int64_t)kb * P.k_ss, koff, tid);
+            load_tile64_async_full<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, voff, tid);
+        } else {
+            load_tile64_async<T>(base, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
+            load_tile64_async<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
+        }
         if (MASK == SHG_MASK_KEY && wave_u == 0) load_row64_async(base + 2 * TL::BYTES, mrow, kb, P.Sk, lane);
     };
     stage(0, 0);
@@ -197,25 +210,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
                 alpha[n] = fast_exp2(m_run[n] - m_use);
                 moved = moved || (m_new != m_run[n]);
                 float rs = 0.f;
-                int keep_lo = 0, keep_hi = 0;              // lane e (< 16) collects mask word e = 4 kt + r
+                uint64_t km[16];                           // mask word e = 4 kt + r: the ballot of "keep" for accumulator element (kt, r)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float p = fast_exp2(s[n][kt][r] - m_use);
                         rs += p;
-                        if (DROP) {
+                        if (DROP) {          // (the 1 / (1 - p) scale is applied once, to the normaliser at the end of the kernel)
                             const bool keep = dropout_keep_run(seed, drop_row[n] + (uint64_t)(kb + 16 * kt + 4 * g), r, P.drop_thr);
-                            const uint64_t m = __builtin_amdgcn_ballot_w64(keep);     // (the compare result itself: no extra instruction)
-                            write_lane_pair(m, 4 * kt + r, keep_lo, keep_hi);
-                            p = keep ? p * P.drop_scale : 0.f;
+                            km[4 * kt + r] = __builtin_amdgcn_ballot_w64(keep);       // (the compare result itself: no extra instruction)
+                            p = keep ? p : 0.f;
                         }
                         s[n][kt][r] = p;
                     }
                 if (DROP) {
                     const int qblk = (int)blockIdx.x * (4 * NB) + wave_u * NB + n;
-                    uint64_t* dst = P.keep + keep_word0(P, b * P.H + h, qblk, kb >> 6);
-                    if (lane < 16) dst[lane] = ((uint64_t)(uint32_t)keep_hi << 32) | (uint32_t)keep_lo;
+                    store_keep_masks(P.keep + keep_word0(P, b * P.H + h, qblk, kb >> 6), km);
                 }
                 rs = xrow_sum(rs);
                 l_run[n] = l_run[n] * alpha[n] + rs;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
         if (qidx[n] < P.Sq) {
-            const float inv = l_run[n] > 0.f ? 1.f / l_run[n] : 0.f;
+            const float inv = l_run[n] > 0.f ? (DROP ? P.drop_scale : 1.f) / l_run[n] : 0.f;
             T* optr = o + ((int64_t)b * P.Sq + qidx[n]) * (P.H * 64) + h * 64;
 #pragma unroll
             for (int d = 0; d < 4; ++d)
@@ -258,6 +269,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
             if (g == 0) lse[((int64_t)b * P.H + h) * P.Sq + qidx[n]] = (m_run[n] + log2f(l_run[n])) * LN2;      // natural log
         }
     }
+    if (DROP) asm volatile("s_dcache_wb" ::: "memory");    // the keep masks left through the scalar data cache
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -307,11 +319,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T*
     for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[n][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const TileLaneOffsets<T> koff = tile_lane_offsets<T>(P.k_ss, tid), voff = tile_lane_offsets<T>(P.v_ss, tid);
     auto stage = [&](int buf, int kb) {
         char* base = smem + buf * STG;
         const int valid = min(64, P.Sk - kb);
-        load_tile64_async<T>(base, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
-        load_tile64_async<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
+        if (valid == 64) {
+            load_tile64_async_full<T>(base, kbase + (int64_t)kb * P.k_ss, koff, tid);
+            load_tile64_async_full<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, voff, tid);
+        } else {
+            load_tile64_async<T>(base, kbase + (int64_t)kb * P.k_ss, P.k_ss, valid, tid);
+            load_tile64_async<T>(base + TL::BYTES, vbase + (int64_t)kb * P.v_ss, P.v_ss, valid, tid);
+        }
         if (MASK == SHG_MASK_KEY && wave_u == 0) load_row64_async(base + 2 * TL::BYTES, mrow, kb, P.Sk, lane);
     };
     // (all ordinary global loads above are consumed before the first direct-to-LDS load is issued)
@@ -464,11 +482,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
     const int64_t keep_qstep = (int64_t)((P.Sk + 63) >> 6) * 16;                  // words per 16-query block
     const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sk;       // wave-uniform, see the forward kernel
     const bool key_tail = (int)(blockIdx.x * (64 * NB) + (wave_u + 1) * (16 * NB)) > P.Sk;   // this wave holds keys past Sk
+    const TileLaneOffsets<T> qoff = tile_lane_offsets<T>(P.q_ss, tid), doff = tile_lane_offsets<T>(P.H * 64, tid);
     auto stage = [&](int buf, int qb) {
         char* base = smem + buf * STG;
         const int valid = min(64, P.Sq - qb);
-        load_tile64_async<T>(base, qbase + (int64_t)qb * P.q_ss, P.q_ss, valid, tid);
-        load_tile64_async<T>(base + TL::BYTES, dbase + (int64_t)qb * (P.H * 64), P.H * 64, valid, tid);
+        if (valid == 64) {
+            load_tile64_async_full<T>(base, qbase + (int64_t)qb * P.q_ss, qoff, tid);
+            load_tile64_async_full<T>(base + TL::BYTES, dbase + (int64_t)qb * (P.H * 64), doff, tid);
+        } else {
+            load_tile64_async<T>(base, qbase + (int64_t)qb * P.q_ss, P.q_ss, valid, tid);
+            load_tile64_async<T>(base + TL::BYTES, dbase + (int64_t)qb * (P.H * 64), P.H * 64, valid, tid);
+        }
         // per-query statistics: 64 floats each, one 4-byte direct-to-LDS load per lane (waves 0 and 1)
         if (wave_u == 0) load_row64_async(base + 2 * TL::BYTES, lse + stat0, qb, P.Sq, lane);
         if (wave_u == 1) load_row64_async(base + 2 * TL::BYTES + 256, delta + stat0, qb, P.Sq, lane);
@@ -654,6 +678,8 @@ extern "C" int shg_attention_fwd(const void* q, const void* k, const void* v, vo
                                  int64_t k_sstride, int64_t v_bstride, int64_t v_sstride, int mask_kind,
                                  const float* mask, float scale, float p_drop, const uint64_t* seed_state,
                                  uint64_t stream_id, uint64_t* keep_mask, void* stream) {
+    SHG_REPEAT(1, shg_attention_fwd(q, k, v, o, lse, dtype, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride,
+                                    mask_kind, mask, scale, p_drop, seed_state, stream_id, keep_mask, stream));
     AttnParams P{q, k, v, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride, mask, scale,
                  dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id, keep_mask};
     if (int e = attn_check(P, dtype, mask_kind, p_drop)) return e;
@@ -676,6 +702,9 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
                                  int64_t dq_sstride, int64_t dk_bstride, int64_t dk_sstride, int64_t dv_bstride,
                                  int64_t dv_sstride, int mask_kind, const float* mask, float scale, float p_drop,
                                  const uint64_t* seed_state, uint64_t stream_id, const uint64_t* keep_mask, void* stream) {
+    SHG_REPEAT(2, shg_attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, dtype, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride,
+                                    v_bstride, v_sstride, dq_bstride, dq_sstride, dk_bstride, dk_sstride, dv_bstride, dv_sstride, mask_kind,
+                                    mask, scale, p_drop, seed_state, stream_id, keep_mask, stream));
     AttnParams P{q, k, v, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride, mask, scale,
                  dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id,
                  const_cast<uint64_t*>(keep_mask)};

@@ -54,9 +54,25 @@ enum Tune {
                                // leaves idle, the smaller tile's extra CU-time costs 0.4-2 % (three interleaved pairs) - "gemm8_tile_m"
     TUNE_ATTN_BWD_FUSED,       // 1: one backward kernel for dQ / dK / dV where available - "attn_bwd_fused"
     TUNE_EPILOGUE_SIDE,        // 1: GEMM row writers issue the loads of `C +=` / activation-backward forms up front - "epilogue_side"
+    TUNE_REPEAT_FAMILY,        // DIAGNOSTIC (0): bit mask of kernel families whose every launch is issued TWICE (all idempotent:
+                               // 1 attention forward, 2 attention backward, 4 LayerNorm forward, 8 LayerNorm backward,
+                               // 16 non-accumulating GEMMs of >= 120 tiles of 256 x 256, 32 smaller non-accumulating GEMMs,
+                               // 64 convolution forward): the step time it adds is what the family costs IN the step, next to
+                               // the other streams' kernels (tools/family_cost.py) - "repeat_family"
     TUNE_COUNT
 };
 int64_t tuning(int key);
+extern thread_local int g_in_repeat;
+// first statement of an exported launch function: re-enters it once when its family's bit is set
+#define SHG_REPEAT(BIT, CALL)                                                    \
+    do {                                                                         \
+        if ((shg::tuning(shg::TUNE_REPEAT_FAMILY) & (BIT)) && !shg::g_in_repeat) { \
+            shg::g_in_repeat = 1;                                                \
+            const int e_ = (CALL);                                               \
+            shg::g_in_repeat = 0;                                                \
+            if (e_) return e_;                                                   \
+        }                                                                        \
+    } while (0)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: one bit per device in a per-instantiation mask
 // (true: the attribute has already been set for the current device)

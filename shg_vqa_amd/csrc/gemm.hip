@@ -1788,6 +1788,9 @@ extern "C" int64_t shg_gemm_streamk_launches(void) { return shg::g_streamk_launc
 extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
                         int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
                         int accumulate, void* stream) {
+    if (!accumulate && dtype_c == SHG_BF16)
+        SHG_REPEAT(((M + 255) / 256) * ((N + 255) / 256) >= 120 ? 16 : 32,
+                   shg_gemm(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, stream));
     return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, SHG_ACT_NONE,
                       nullptr, stream);
 }
@@ -1826,6 +1829,9 @@ extern "C" int shg_gemm_dact(const void* dy, const void* w, void* dx, const void
 extern "C" int shg_gemm_act(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
                             int act, void* pre, float p_drop, const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+    if (dtype_c == SHG_BF16)
+        SHG_REPEAT(((M + 255) / 256) * ((N + 255) / 256) >= 120 ? 16 : 32,
+                   shg_gemm_act(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, act, pre, p_drop, seed_state, stream_id, stream));
     if (int e = drop_args_ok(p_drop, seed_state, N)) return e;
     return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 0, act, pre, stream, p_drop,
                       seed_state, stream_id);
@@ -1869,6 +1875,7 @@ extern "C" int shg_streamk_workspace_init(void* ws, void* stream) {
 extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
                                    int H, int W, int Cin, int Cout, int act, int pad_out, void* y_pre,
                                    const void* workspace, void* streamk_ws, void* stream) {
+    SHG_REPEAT(64, shg_conv3d_k533_fwd(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, workspace, streamk_ws, stream));
     if (!x || !w || !y) return fail_arg("conv3d_fwd: null pointer");
     if (streamk_ws && !al16(streamk_ws)) return fail_arg("conv3d_fwd: streamk workspace must be 16-byte aligned");
     if (y_pre && !al16(y_pre)) return fail_arg("conv3d_fwd: y_pre must be 16-byte aligned");

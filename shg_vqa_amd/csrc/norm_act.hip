@@ -568,6 +568,8 @@ extern "C" int shg_bias_act_drop_res_ln_fwd_pos(const void* x, const float* bias
                                                 const void* pos, void* y_pos, int dtype, int64_t rows, int cols, int act,
                                                 float eps, float p_drop, const uint64_t* seed_state, uint64_t stream_id,
                                                 void* stream) {
+    SHG_REPEAT(4, shg_bias_act_drop_res_ln_fwd_pos(x, bias, residual, gamma, beta, y, z_out, mean, rstd, pos, y_pos, dtype, rows, cols, act,
+                                                   eps, p_drop, seed_state, stream_id, stream));
     if (!x || !gamma || !beta || !y || !mean || !rstd) return fail_arg("ln_fwd: null pointer");
     if ((pos == nullptr) != (y_pos == nullptr)) return fail_arg("ln_fwd: pos and y_pos go together");
     if (int e = check_cols(dtype, cols, "ln_fwd: cols must be a multiple of the 16-byte vector and <= 2048 (f32) / 4096 (bf16)")) return e;
@@ -709,6 +711,8 @@ extern "C" int shg_bias_act_drop_res_ln_bwd(const void* dy, const void* z, const
                                             float* dbias_partial, int n_partials, int dtype, int64_t rows, int cols,
                                             int act, float p_drop, const uint64_t* seed_state, uint64_t stream_id,
                                             void* stream) {
+    SHG_REPEAT(8, shg_bias_act_drop_res_ln_bwd(dy, z, x, bias, gamma, mean, rstd, dx, dres, dgamma_partial, dbeta_partial, dbias_partial,
+                                               n_partials, dtype, rows, cols, act, p_drop, seed_state, stream_id, stream));
     if (!dy || !z || !gamma || !mean || !rstd) return fail_arg("ln_bwd: null pointer");
     if (act != SHG_ACT_NONE && !x) return fail_arg("ln_bwd: x is required when act != NONE");
     if (int e = check_cols(dtype, cols, "ln_bwd: unsupported cols")) return e;

@@ -9,17 +9,23 @@ dev = torch.device("cuda", 0)
 bf = torch.bfloat16
 
 
-def timeit(fn, n=20):
-    for _ in range(3):
+def timeit(fn, n=50, reps=5):
+    """us per launch: the median of `reps` blocks of `n` back-to-back launches (single blocks of 20 launches scattered by +-8 % on
+    one box: clocks move with what ran before)."""
+    for _ in range(5):
         fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    s.record()
-    for _ in range(n):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e3          # us
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / n * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 which = sys.argv[1:] or ["attn", "ln", "wgrad"]
