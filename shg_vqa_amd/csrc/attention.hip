@@ -275,8 +275,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P, T* __restri
 // ------------------------------------------------------------------------------------------------
 // backward, dQ (also produces delta = rowsum(dO o O))
 // ------------------------------------------------------------------------------------------------
+// (second launch bound: waves per SIMD the register allocation must leave room for - the bf16 single-block key-mask kernel of the
+//  relation layers sits six registers above the 128 of four waves per SIMD without it: 142 -> 139.8 us for dQ + dK/dV at 393 x 393;
+//  the same bound on the dK/dV kernel - 196 -> 168 registers, three waves - spills inside its loops: 233 us)
 template <typename T, int MASK, int NB, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P, const T* __restrict__ o, const T* __restrict__ d_o,
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && NB == 1 && MASK == SHG_MASK_KEY) ? 4 : 1) void attn_bwd_dq_kernel(AttnParams P, const T* __restrict__ o, const T* __restrict__ d_o,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           T* __restrict__ dq, int64_t dq_bs, int64_t dq_ss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
