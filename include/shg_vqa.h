@@ -204,6 +204,9 @@ int shg_colsum_accumulate(const void* x, int dtype, int64_t rows, int cols, int6
  * call draws the keep decisions and writes them to keep_mask as lane masks (shg_attention_keep_mask_bytes(B, H, Sq, Sk) bytes,
  * 128-byte aligned, caller-owned; layout in csrc/attention.hip); the backward call of the same attention reads them instead of
  * re-drawing.  keep_mask is required when p_drop > 0 and ignored (may be NULL) otherwise.
+ * dbias_q / dbias_k / dbias_v (backward; each fp32 [H * 64] or NULL): the column sums of dq / dk / dv over all rows are ADDED to
+ * them (fp32 atomics) - the bias gradients of the query / key / value projections (BertSelfAttention's nn.Linear biases,
+ * modeling_capsbert.py:375-380; nn.MultiheadAttention.in_proj_bias), without a separate pass over the gradient buffers.
  */
 int64_t shg_attention_keep_mask_bytes(int B, int H, int Sq, int Sk);
 int shg_attention_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int H,
@@ -216,7 +219,8 @@ int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o
                       int64_t v_bstride, int64_t v_sstride, int64_t dq_bstride, int64_t dq_sstride,
                       int64_t dk_bstride, int64_t dk_sstride, int64_t dv_bstride, int64_t dv_sstride,
                       int mask_kind, const float* mask, float scale, float p_drop, const uint64_t* seed_state,
-                      uint64_t stream_id, const uint64_t* keep_mask, void* stream);
+                      uint64_t stream_id, const uint64_t* keep_mask, float* dbias_q, float* dbias_k, float* dbias_v,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM on the matrix cores:  C[M,N] = A . B (+ bias[N]), fp32 accumulation.

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "shg_attention_keep_mask_bytes": ([I, I, I, I], c_int64),
     "shg_attention_fwd": ([P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, I, P, F, F, P, U, P, P], c_int),
     "shg_attention_bwd": ([P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, L,
-                           I, P, F, F, P, U, P, P], c_int),
+                           I, P, F, F, P, U, P, P, P, P, P], c_int),
     "shg_gemm": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P], c_int),
     "shg_gemm_dact": ([P, P, P, P, P, I, L, L, L, L, L, L, I, F, P, U, P], c_int),
     "shg_gemm_act": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P, F, P, U, P], c_int),

@@ -55,7 +55,35 @@ struct AttnParams {
     const uint64_t* seed_state;
     uint64_t stream_id;
     uint64_t* keep;            // dropout lane masks [B*H][ceil(Sq/16)][ceil(Sk/64)][16] (written by forward, read by backward)
+    float *dbq, *dbk, *dbv;    // backward: bias gradients of the q / k / v projections, fp32 [H * 64] each, or null
 };
+
+// Column sums of a head's gradient block, added into the projection's bias gradient: acc[n][d][r] is the gradient of feature
+// 16 d + 4 g + r for the lane's row (query or key li of block n).  The rows of a wave are summed over the 16 lanes of a DPP row,
+// the waves of the workgroup through LDS, and 64 lanes add the head's 64 features with one atomic instruction.  (The bias
+// gradients of the q / k / v projections used to be separate column-sum kernels over the [rows, 3 H] gradient - 59 launches per
+// step which, issued twice, cost +0.97 ms per step: tools/family_cost.py.)
+template <int NB>
+__device__ __forceinline__ void head_colsum(const f32x4 (&acc)[NB][4], const bool (&valid)[NB], float mul, float* dst /* + head offset */,
+                                            float* red /* LDS [4][64] */, int tid) {
+    const int wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) v += valid[n] ? acc[n][d][r] : 0.f;
+            v += dpp_take<0xB1, 0xF>(v);         // quad_perm [1,0,3,2]
+            v += dpp_take<0x4E, 0xF>(v);         // quad_perm [2,3,0,1]
+            v += dpp_take<0x141, 0xF>(v);        // row_half_mirror
+            v += dpp_take<0x140, 0xF>(v);        // row_mirror: every lane of the row of 16 holds the row's sum
+            if (li == 0) red[wave * 64 + 16 * d + 4 * g + r] = v * mul;
+        }
+    __syncthreads();
+    if (tid < 64) atomicAdd(dst + tid, red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid]);
+    __syncthreads();
+}
 
 // first of the 16 mask words of (head bh, 16-query block qblk, 64-key tile ktile)
 __device__ __forceinline__ int64_t keep_word0(const AttnParams& P, int bh, int qblk, int ktile) {
@@ -436,6 +464,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NB == 1 && MASK == SHG_MASK
                 for (int r = 0; r < 4; ++r) out[16 * d + 4 * g + r] = from_f32<T>(acc[n][d][r] * P.scale);
         }
     }
+    if (P.dbq) {                                       // (wave-uniform; the operand buffers are free after the loop's last barrier)
+        bool valid[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) valid[n] = qidx[n] < P.Sq;
+        head_colsum<NB>(acc, valid, P.scale, P.dbq + h * 64, reinterpret_cast<float*>(smem), tid);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -618,6 +652,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                 }
         }
     }
+    if (P.dbk || P.dbv) {
+        bool valid[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) valid[n] = kidx[n] < P.Sk;
+        if (P.dbk) head_colsum<NB>(acc_k, valid, P.scale, P.dbk + h * 64, reinterpret_cast<float*>(smem), tid);
+        if (P.dbv) head_colsum<NB>(acc_v, valid, 1.f, P.dbv + h * 64, reinterpret_cast<float*>(smem), tid);
+    }
 }
 
 static int attn_check(const AttnParams& P, int dtype, int mask_kind, float p_drop) {
@@ -684,7 +725,8 @@ extern "C" int shg_attention_fwd(const void* q, const void* k, const void* v, vo
     SHG_REPEAT(1, shg_attention_fwd(q, k, v, o, lse, dtype, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride,
                                     mask_kind, mask, scale, p_drop, seed_state, stream_id, keep_mask, stream));
     AttnParams P{q, k, v, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride, mask, scale,
-                 dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id, keep_mask};
+                 dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id, keep_mask,
+                 nullptr, nullptr, nullptr};
     if (int e = attn_check(P, dtype, mask_kind, p_drop)) return e;
     if (!o || !lse) return fail_arg("attention_fwd: null output");
     hipStream_t st = (hipStream_t)stream;
@@ -704,13 +746,15 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
                                  int64_t k_sstride, int64_t v_bstride, int64_t v_sstride, int64_t dq_bstride,
                                  int64_t dq_sstride, int64_t dk_bstride, int64_t dk_sstride, int64_t dv_bstride,
                                  int64_t dv_sstride, int mask_kind, const float* mask, float scale, float p_drop,
-                                 const uint64_t* seed_state, uint64_t stream_id, const uint64_t* keep_mask, void* stream) {
+                                 const uint64_t* seed_state, uint64_t stream_id, const uint64_t* keep_mask, float* dbias_q,
+                                 float* dbias_k, float* dbias_v, void* stream) {
+    // (the repeated launch of the diagnostic switch leaves the bias gradients out: they accumulate)
     SHG_REPEAT(2, shg_attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, dtype, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride,
                                     v_bstride, v_sstride, dq_bstride, dq_sstride, dk_bstride, dk_sstride, dv_bstride, dv_sstride, mask_kind,
-                                    mask, scale, p_drop, seed_state, stream_id, keep_mask, stream));
+                                    mask, scale, p_drop, seed_state, stream_id, keep_mask, nullptr, nullptr, nullptr, stream));
     AttnParams P{q, k, v, B, H, Sq, Sk, q_bstride, q_sstride, k_bstride, k_sstride, v_bstride, v_sstride, mask, scale,
                  dropout_threshold(p_drop), p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f, seed_state, stream_id,
-                 const_cast<uint64_t*>(keep_mask)};
+                 const_cast<uint64_t*>(keep_mask), dbias_q, dbias_k, dbias_v};
     if (int e = attn_check(P, dtype, mask_kind, p_drop)) return e;
     if (!o || !d_o || !lse || !delta || !dq || !dk || !dv) return fail_arg("attention_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;

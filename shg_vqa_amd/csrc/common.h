@@ -57,8 +57,11 @@ enum Tune {
     TUNE_REPEAT_FAMILY,        // DIAGNOSTIC (0): bit mask of kernel families whose every launch is issued TWICE (all idempotent:
                                // 1 attention forward, 2 attention backward, 4 LayerNorm forward, 8 LayerNorm backward,
                                // 16 non-accumulating GEMMs of >= 120 tiles of 256 x 256, 32 smaller non-accumulating GEMMs,
-                               // 64 convolution forward): the step time it adds is what the family costs IN the step, next to
-                               // the other streams' kernels (tools/family_cost.py) - "repeat_family"
+                               // 64 convolution forward; and, changing the gradients (timing runs only): 128 grouped weight
+                               // gradients, 256 convolution weight gradients, 512 convolution input gradient (idempotent),
+                               // 1024 GEMM + activation backward, 2048 accumulating bf16 GEMMs, 4096 bias column sums): the
+                               // step time it adds is what the family costs IN the step, next to the other streams' kernels
+                               // (tools/family_cost.py) - "repeat_family"
     TUNE_COUNT
 };
 int64_t tuning(int key);

@@ -273,16 +273,21 @@ static int attn_bwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int
         const char* q = (const char*)s.qkv;
         char* dq = (char*)w.dqkv;
         const int64_t qb = (int64_t)Sq * 3 * H, qs = 3 * H;
+        // the bias gradients of the projections are column sums of dq / dk / dv: the attention backward kernels add them
+        // (self: a = [q; k; v]; decoder self: a = [q; k] of tgt + pos, b = v of tgt)
+        float* gbq = L->a.gb;
+        float* gbk = L->a.gb ? L->a.gb + H : nullptr;
+        float* gbv = mode == SHG_ATTN_SELF ? (L->a.gb ? L->a.gb + 2 * H : nullptr) : L->b.gb;
         CK(shg_attention_bwd(q, q + H * es, q + 2 * H * es, s.o, w.d_o, s.lse, w.delta, dq, dq + H * es, dq + 2 * H * es, dt, B, heads,
                              Sq, Sk, qb, qs, qb, qs, qb, qs, qb, qs, qb, qs, qb, qs, L->mask_kind, L->mask, L->scale, pa,
-                             R->seed_state, sid, s.keep, st));
+                             R->seed_state, sid, s.keep, gbq, gbk, gbv, st));
         if (mode == SHG_ATTN_SELF) {
-            CK(wgrad(R, L->a, dq, 3 * H, x, H, rq, 3 * H, H, true));
+            CK(wgrad(R, L->a, dq, 3 * H, x, H, rq, 3 * H, H, false));
             if (dx) CK(shg_gemm(dq, L->a.w, dx, nullptr, dt, dt, rq, H, 3 * H, 3 * H, H, H, 1, 0, 1, st));
         } else {
             const char* dv = dq + 2 * H * es;
-            CK(wgrad(R, L->a, dq, 3 * H, xpos, H, rq, 2 * H, H, true));
-            CK(wgrad(R, L->b, dv, 3 * H, x, H, rq, H, H, true));
+            CK(wgrad(R, L->a, dq, 3 * H, xpos, H, rq, 2 * H, H, false));
+            CK(wgrad(R, L->b, dv, 3 * H, x, H, rq, H, H, false));
             if (dxpos) CK(shg_gemm(dq, L->a.w, dxpos, nullptr, dt, dt, rq, H, 2 * H, 3 * H, H, H, 1, 0, 0, st));
             if (dx) CK(shg_gemm(dv, L->b.w, dx, nullptr, dt, dt, rq, H, H, 3 * H, H, H, 1, 0, 1, st));
         }
@@ -290,10 +295,12 @@ static int attn_bwd(const shg_attn_sublayer_t* L, const shg_run_t* R, int B, int
         const char* k = (const char*)s.kv;
         char* dk = (char*)w.dkv;
         const int64_t qb = (int64_t)Sq * H, qs = H, kb = (int64_t)Sk * 2 * H, ks = 2 * H;
+        // (cross: a = q of the queries, b = [k; v] of the memory)
         CK(shg_attention_bwd(s.qkv, k, k + H * es, s.o, w.d_o, s.lse, w.delta, w.dqkv, dk, dk + H * es, dt, B, heads, Sq, Sk, qb, qs,
-                             kb, ks, kb, ks, qb, qs, kb, ks, kb, ks, L->mask_kind, L->mask, L->scale, pa, R->seed_state, sid, s.keep, st));
-        CK(wgrad(R, L->a, w.dqkv, H, mode == SHG_ATTN_DEC_CROSS ? xpos : x, H, rq, H, H, true));
-        CK(wgrad(R, L->b, w.dkv, 2 * H, mem, H, rk, 2 * H, H, true));
+                             kb, ks, kb, ks, qb, qs, kb, ks, kb, ks, L->mask_kind, L->mask, L->scale, pa, R->seed_state, sid, s.keep,
+                             L->a.gb, L->b.gb, L->b.gb ? L->b.gb + H : nullptr, st));
+        CK(wgrad(R, L->a, w.dqkv, H, mode == SHG_ATTN_DEC_CROSS ? xpos : x, H, rq, H, H, false));
+        CK(wgrad(R, L->b, w.dkv, 2 * H, mem, H, rk, 2 * H, H, false));
         if (mode == SHG_ATTN_CROSS) {
             if (dx) CK(shg_gemm(w.dqkv, L->a.w, dx, nullptr, dt, dt, rq, H, H, H, H, H, 1, 0, 1, st));
         } else if (dxpos) {

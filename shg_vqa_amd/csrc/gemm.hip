@@ -1707,6 +1707,7 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
 
 // Weight gradients of several nn.Linear layers in one grid (include/shg_vqa.h: shg_wgrad_group).
 extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtype, void* stream) {
+    SHG_REPEAT(128, shg_wgrad_group(probs, n, dtype, stream));          // (accumulating: the gradients double - timing runs only)
     if (!probs || n < 0) return fail_arg("wgrad_group: bad argument");
     if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("wgrad_group: bad dtype");
     hipStream_t st = (hipStream_t)stream;
@@ -1791,6 +1792,8 @@ extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias
     if (!accumulate && dtype_c == SHG_BF16)
         SHG_REPEAT(((M + 255) / 256) * ((N + 255) / 256) >= 120 ? 16 : 32,
                    shg_gemm(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, stream));
+    if (accumulate && dtype_c == SHG_BF16)      // (`C +=` onto a residual gradient: doubles that contribution - timing runs only)
+        SHG_REPEAT(2048, shg_gemm(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, stream));
     return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, SHG_ACT_NONE,
                       nullptr, stream);
 }
@@ -1805,6 +1808,7 @@ static int drop_args_ok(float p_drop, const uint64_t* seed_state, int64_t N) {
 extern "C" int shg_gemm_dact(const void* dy, const void* w, void* dx, const void* pre, float* dbias, int dtype, int64_t M,
                              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int act, float p_drop,
                              const uint64_t* seed_state, uint64_t stream_id, void* stream) {
+    SHG_REPEAT(1024, shg_gemm_dact(dy, w, dx, pre, dbias, dtype, M, N, K, lda, ldb, ldc, act, p_drop, seed_state, stream_id, stream));
     if (!dy || !w || !dx || !pre) return fail_arg("gemm_dact: null pointer");
     if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm_dact: sizes must be positive");
     if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("gemm_dact: bad dtype");
@@ -1908,6 +1912,7 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
 
 extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                                            int Cin, int Cout, int c0, int cn, int accumulate, const void* workspace, void* stream) {
+    SHG_REPEAT(256, shg_conv3d_k533_wgrad_slice(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, workspace, stream));
     if (!x || !dy || !dw) return fail_arg("conv3d_wgrad: null pointer");
     if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
     if (c0 < 0 || cn < 1 || c0 + cn > Cout || c0 % 8 || cn % 8) return fail_arg("conv3d_wgrad: bad output-channel slice (multiples of 8 inside [0, Cout))");
@@ -1968,6 +1973,7 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
 
 extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
                                      int Cin, int Cout, const void* workspace, void* stream) {
+    SHG_REPEAT(512, shg_conv3d_k533_dgrad(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, workspace, stream));
     // dx[b,t,h,w,ci] = sum_{tap',co} dYp[b, t+kt', h+kh', w+kw', co] * W[co][44-tap'][ci]; dYp = dy padded by
     // 4 in T and 1 in H/W, so this is the forward gather over dYp with the weight read "contraction strided".
     if (!dy_padded || !w || !dx) return fail_arg("conv3d_dgrad: null pointer");

@@ -532,6 +532,7 @@ static int colsum_accumulate_t(const T* x, int64_t rows, int cols, int64_t ld, f
 }
 
 extern "C" int shg_colsum_accumulate(const void* x, int dtype, int64_t rows, int cols, int64_t ld, float* out, void* stream) {
+    SHG_REPEAT(4096, shg_colsum_accumulate(x, dtype, rows, cols, ld, out, stream));
     if (!x || !out || rows <= 0 || cols <= 0 || cols > 4096 || ld < cols) return fail_arg("colsum_accumulate: bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SHG_F32) return colsum_accumulate_t<float>((const float*)x, rows, cols, ld, out, st);

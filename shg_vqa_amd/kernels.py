@@ -326,9 +326,10 @@ def attention_fwd(q, k, v, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p
 
 
 def attention_bwd(q, k, v, o, d_o, lse, dq, dk, dv, heads, mask_kind=MASK_NONE, mask=None, scale=0.125, p_drop=0.0,
-                  seed_state=None, stream_id=0, keep_mask=None):
+                  seed_state=None, stream_id=0, keep_mask=None, dbias=(None, None, None)):
     """Writes dq/dk/dv (views with the same layout rules as q/k/v).  With dropout: keep_mask = the buffer the forward call
-    filled (default: the one attention_fwd attached to `lse`)."""
+    filled (default: the one attention_fwd attached to `lse`).  dbias = (dbias_q, dbias_k, dbias_v): fp32 [H*64] vectors (or
+    None) that receive += the column sums of dq / dk / dv."""
     if p_drop > 0.0 and keep_mask is None:
         keep_mask = getattr(lse, "_shg_keep", None)
         _need(keep_mask is not None, "attention_bwd with dropout needs the forward call's keep_mask")
@@ -346,11 +347,15 @@ def attention_bwd(q, k, v, o, d_o, lse, dq, dk, dv, heads, mask_kind=MASK_NONE, 
     _need(sq2 == sq and sk2 == sk and sk3 == sk and dq.dtype == q.dtype and dk.dtype == q.dtype and dv.dtype == q.dtype,
           "gradient buffers must match q/k/v")
     mask = _mask_args(mask_kind, mask, b, sq, sk)
+    for t in dbias:
+        if t is not None:
+            _dev(t)
+            _need(t.dtype == torch.float32 and t.numel() == heads * 64 and t.is_contiguous(), "dbias vectors must be contiguous fp32 [H*64]")
     delta = torch.empty((b, heads, sq), dtype=torch.float32, device=q.device)
     _lib.call("shg_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
               delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), _dt(q), b, heads, sq, sk, qb, qs, kb, ks,
               vb, vs, dqb, dqs, dkb, dks, dvb, dvs, mask_kind, _p(mask), float(scale), float(p_drop), _p(seed_state),
-              int(stream_id), _p(keep_mask), _stream())
+              int(stream_id), _p(keep_mask), _p(dbias[0]), _p(dbias[1]), _p(dbias[2]), _stream())
 
 
 # ------------------------------------------------------------------------------------------------

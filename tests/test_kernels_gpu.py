@@ -261,6 +261,39 @@ def test_attention_fwd_bwd(K, dtype, Sq, Sk, mask_kind):
     assert (dqkv[:, :, :H * 64] == 0).all() and (dqkv[:, :, 2 * H * 64:] == 0).all()   # nothing outside the views
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Sq,Sk,mask_kind,p", [(393, 393, 1, 0.1), (128, 128, 2, 0.0), (48, 393, 0, 0.15), (40, 177, 1, 0.0)])
+def test_attention_bwd_adds_projection_bias_gradients(K, dtype, Sq, Sk, mask_kind, p):
+    """shg_attention_bwd's dbias_q / dbias_k / dbias_v: the column sums of dq / dk / dv over all (batch, position) rows, ADDED to
+    what the vectors hold (the bias gradients of the q / k / v projections, mc:375-380; nn.MultiheadAttention.in_proj_bias) -
+    including the last partial row blocks (393 = 24 x 16 + 9 rows: the clamped duplicate rows must not be counted)."""
+    gen = torch.Generator().manual_seed(Sq + 7 * Sk)
+    B, H = 3, 4
+    q = torch.randn(B, Sq, H * 64, generator=gen).to(dtype).to(DEV)
+    k = torch.randn(B, Sk, H * 64, generator=gen).to(dtype).to(DEV)
+    v = torch.randn(B, Sk, H * 64, generator=gen).to(dtype).to(DEV)
+    do = torch.randn(B, Sq, H * 64, generator=gen).to(dtype).to(DEV)
+    mask = None
+    if mask_kind == 1:
+        m01 = torch.ones(B, Sk)
+        m01[0, Sk // 2:] = 0
+        mask = ((1.0 - m01) * -10000.0).to(DEV)
+    elif mask_kind == 2:
+        from oracle import shg_ref
+        mask = shg_ref.frame_causal_mask(16, Sq // 16).to(DEV).contiguous()
+    seed = torch.tensor([5, 9], dtype=torch.int64, device=DEV)
+    o, lse = K.attention_fwd(q, k, v, H, mask_kind, mask, 0.125, p, seed, 4)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    init = [torch.randn(H * 64, generator=gen).to(DEV) for _ in range(3)]
+    db = [t.clone() for t in init]
+    K.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, H, mask_kind, mask, 0.125, p, seed, 4, dbias=tuple(db))
+    ref = K.attention_bwd(q, k, v, o, do, lse, torch.empty_like(q), torch.empty_like(k), torch.empty_like(v), H, mask_kind, mask, 0.125, p, seed, 4)
+    for got, base, grad, rows in ((db[0], init[0], dq, B * Sq), (db[1], init[1], dk, B * Sk), (db[2], init[2], dv, B * Sk)):
+        exp = base.double() + grad.double().sum((0, 1))                 # (the kernel sums the fp32 values before their rounding)
+        tol = (2e-4 if dtype == torch.float32 else 2e-2) * math.sqrt(rows) * max(1.0, grad.float().abs().max().item())
+        assert torch.allclose(got.double(), exp, rtol=2e-3, atol=tol), (got.double() - exp).abs().max().item()
+
+
 def test_attention_operand_layout_with_integer_data(K):
     """A = I style check with ASYMMETRIC data: exact small integers expose a transposed fragment."""
     B, H, S = 1, 1, 64

@@ -27,7 +27,9 @@ for i in range(3):
     tr.train_step(batches[i % 4])
 torch.cuda.synchronize()
 fams = [(0, "baseline"), (1, "attention forward"), (2, "attention backward"), (4, "LayerNorm forward"), (8, "LayerNorm backward"),
-        (16, "GEMMs >= 120 tiles of 256 x 256 (non-accumulating)"), (32, "smaller GEMMs (non-accumulating)"), (64, "convolution forward")]
+        (16, "GEMMs >= 120 tiles of 256 x 256 (non-accumulating)"), (32, "smaller GEMMs (non-accumulating)"), (64, "convolution forward"),
+        (128, "grouped weight gradients"), (256, "convolution weight gradients"), (512, "convolution input gradient"),
+        (1024, "GEMM + activation backward (dact)"), (2048, "accumulating bf16 GEMMs (C += A.B)"), (4096, "bias column sums")]
 res = {m: [] for m, _ in fams}
 for r in range(rounds):
     for m, _ in fams:
