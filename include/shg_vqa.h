@@ -38,6 +38,12 @@ extern "C" {
 #define SHG_ACT_NONE 0
 #define SHG_ACT_GELU 1 /* erf form, modeling_capsbert.py:127-133 */
 #define SHG_ACT_RELU 2 /* transformer.py:195 (decoder FFN) */
+/* shg_gemm_act: OR-ed to the activation code, `pre` receives act'(A . B + bias) instead of the pre-activation (bf16 outputs only);
+ * shg_gemm_dact then takes act = SHG_ACT_SAVED_GRAD and multiplies by the stored derivative: the erf-GELU derivative (an exponential,
+ * a reciprocal and a degree-5 polynomial per element) is computed once, in the forward epilogue next to the GELU itself with which it
+ * shares all of that, instead of in the input-gradient GEMM's epilogue where nothing overlaps it (12 576 x 3 072: 105 -> 82 us). */
+#define SHG_ACT_SAVE_GRAD 0x100
+#define SHG_ACT_SAVED_GRAD 3
 
 #define SHG_MASK_NONE 0
 #define SHG_MASK_KEY 1  /* additive fp32 [B, Sk]   (BERT (1-m)*-1e4 masks, modeling_capsbert.py:1826-1842) */

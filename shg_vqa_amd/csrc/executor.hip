@@ -356,13 +356,20 @@ static int ffn_args_ok(const shg_ffn_sublayer_t* L, const shg_run_t* R, int64_t 
     return 0;
 }
 
+// (forward and backward of a call pair must agree: training / dtype / dropout setting do not change in between)
+static bool ffn_saves_grad(const shg_ffn_sublayer_t* L, const shg_run_t* R) {
+    return R->dtype == SHG_BF16 && L->act == SHG_ACT_GELU && !(R->training && L->p_inner > 0.f);
+}
+
 static int ffn_fwd(const shg_ffn_sublayer_t* L, const shg_run_t* R, int64_t rows, int H, int F, const void* x, void* y,
                    const void* pos, void* y_pos, void* saved, uint64_t sid) {
     const int dt = R->dtype;
     const float pi = R->training ? L->p_inner : 0.f, po = R->training ? L->p_out : 0.f;
     void* st = R->stream;
     FfnSaved s = ffn_saved(saved, dt, rows, H, F);
-    CK(shg_gemm_act(x, L->l1.w, s.h, L->l1.bias, dt, dt, rows, F, H, H, H, F, 1, 1, L->act, s.pre, pi, R->seed_state, sid, st));
+    // bf16, GELU, no inner dropout (the BERT blocks): `pre` keeps the GELU's derivative, computed beside the GELU (ffn_bwd below)
+    const int act_fwd = ffn_saves_grad(L, R) ? (L->act | SHG_ACT_SAVE_GRAD) : L->act;
+    CK(shg_gemm_act(x, L->l1.w, s.h, L->l1.bias, dt, dt, rows, F, H, H, H, F, 1, 1, act_fwd, s.pre, pi, R->seed_state, sid, st));
     CK(shg_gemm(s.h, L->l2.w, s.t, nullptr, dt, dt, rows, H, F, F, F, H, 1, 1, 0, st));
     CK(shg_bias_act_drop_res_ln_fwd_pos(s.t, L->l2.bias, x, L->ln.gamma, L->ln.beta, y, s.z, s.mean, s.rstd, pos, y_pos, dt, rows, H,
                                         SHG_ACT_NONE, L->ln.eps, po, R->seed_state, sid + 1, st));
@@ -383,7 +390,8 @@ static int ffn_bwd(const shg_ffn_sublayer_t* L, const shg_run_t* R, int64_t rows
     CK(finish_ln_grads(R, L->ln, L->l2.gb, w.parts, w.n_part, H));
     CK(wgrad(R, L->l2, w.dt, H, s.h, F, rows, H, F, false));
     // activation (and inner dropout) backward + linear1's bias gradient in the input-gradient GEMM's epilogue
-    CK(shg_gemm_dact(w.dt, L->l2.w, w.dpre, s.pre, L->l1.gb, dt, rows, F, H, H, F, F, L->act, pi, R->seed_state, sid, st));
+    CK(shg_gemm_dact(w.dt, L->l2.w, w.dpre, s.pre, L->l1.gb, dt, rows, F, H, H, F, F, ffn_saves_grad(L, R) ? SHG_ACT_SAVED_GRAD : L->act, pi,
+                     R->seed_state, sid, st));
     CK(wgrad(R, L->l1, w.dpre, F, x, H, rows, F, H, false));
     if (dx) CK(shg_gemm(w.dpre, L->l1.w, dx, nullptr, dt, dt, rows, H, F, F, H, H, 1, 0, 1, st));      // dx = residual gradient + dpre W1
     return 0;

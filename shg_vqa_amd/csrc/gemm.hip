@@ -288,6 +288,7 @@ template <typename TC> struct Epilogue {
     const uint64_t* seed_state;
     uint64_t stream_id;
     int no_side;              // 1: the row writers' up-front-load forms are switched off ("epilogue_side" tuning switch, A/B runs)
+    int save_grad;            // forward: `pre` receives act'(u) instead of u (SHG_ACT_SAVE_GRAD)
 };
 
 __device__ __forceinline__ float act_grad_rt(float u, int act, bool fast) {
@@ -310,7 +311,23 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_ct(float x) {
 template <int ACT, bool FAST> __device__ __forceinline__ float act_grad_ct(float u) {
     if (ACT == SHG_ACT_GELU) return FAST ? gelu_fast_grad(u) : gelu_erf_grad(u);
     if (ACT == SHG_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    if (ACT == SHG_ACT_SAVED_GRAD) return u;          // the forward stored the derivative itself
     return 1.f;
+}
+// activation and its derivative together (forward epilogue with SHG_ACT_SAVE_GRAD): the fast GELU's parts serve both
+template <int ACT> __device__ __forceinline__ void act_and_grad_fast(float x, float& y, float& g) {
+    if (ACT == SHG_ACT_GELU) {
+        float cdf, e;
+        gelu_fast_parts(x, cdf, e);
+        y = x * cdf;
+        g = fmaf(x * 0.39894228040143267794f, e, cdf);
+    } else if (ACT == SHG_ACT_RELU) {
+        y = fmaxf(x, 0.f);
+        g = x > 0.f ? 1.f : 0.f;
+    } else {
+        y = x;
+        g = 1.f;
+    }
 }
 template <bool FAST = false> __device__ __forceinline__ float apply_act(float x, int act) {
     if (act == SHG_ACT_GELU) return FAST ? gelu_fast(x) : gelu_erf(x);
@@ -332,6 +349,7 @@ template <> struct RowWriter<bf16_t> {
                                int64_t N, int lane, int gap = 0, float* csum_carry = nullptr) {
         if (ep.act == SHG_ACT_GELU) run_act<SHG_ACT_GELU, SIDE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
         else if (ep.act == SHG_ACT_RELU) run_act<SHG_ACT_RELU, SIDE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
+        else if (SIDE && ep.act == SHG_ACT_SAVED_GRAD) run_act<SHG_ACT_SAVED_GRAD, SIDE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
         else run_act<SHG_ACT_NONE, SIDE, ROWS>(stage, ep, mbase, nbase, M, N, lane, gap, csum_carry);
     }
     template <int ACT, bool SIDE, int ROWS>
@@ -478,6 +496,14 @@ template <> struct RowWriter<bf16_t> {
                     for (int r = 0; r < 8; ++r) {
                         const float a = act_ct<ACT, true>(u[r]);
                         o[r] = (bf16_t)(dropout_keep_run(dseed, (uint64_t)(m * N + n), r, ep.drop_thr) ? a * ep.drop_scale : 0.f);
+                    }
+                } else if (pre && ep.save_grad) {             // activation and derivative from shared parts; `pre` keeps the derivative
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float y, gd;
+                        act_and_grad_fast<ACT>(u[r], y, gd);
+                        o[r] = (bf16_t)y;
+                        u[r] = gd;
                     }
                 } else {
 #pragma unroll
@@ -1668,7 +1694,7 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 static int gemm_entry(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
                       int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
                       int accumulate, int act, void* pre, void* stream, float p_drop = 0.f,
-                      const uint64_t* seed_state = nullptr, uint64_t stream_id = 0) {
+                      const uint64_t* seed_state = nullptr, uint64_t stream_id = 0, int save_grad = 0) {
     if (!a || !b || !c) return fail_arg("gemm: null pointer");
     if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm: sizes must be positive");
     if ((dtype_ab != SHG_F32 && dtype_ab != SHG_BF16) || (dtype_c != SHG_F32 && dtype_c != SHG_BF16)) return fail_arg("gemm: bad dtype");
@@ -1700,8 +1726,9 @@ static int gemm_entry(const void* a, const void* b, void* c, const float* bias, 
         return dtype_ab == SHG_F32 ? gemm_dispatch<float, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st)
                                    : gemm_dispatch<bf16_t, float>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
     }
+    if (save_grad && !vec_ok) return fail_arg("gemm: SHG_ACT_SAVE_GRAD needs 16-byte aligned rows of C and pre");
     Epilogue<bf16_t> ep{(bf16_t*)c, ldc, bias, nullptr, act, accumulate, vec_ok, (bf16_t*)pre, 0, nullptr, nullptr, dthr, dscale, seed_state, stream_id,
-                        tuning(TUNE_EPILOGUE_SIDE) ? 0 : 1};
+                        tuning(TUNE_EPILOGUE_SIDE) ? 0 : 1, save_grad};
     return gemm_dispatch<bf16_t, bf16_t>(a, b, ep, M, N, K, lda, ldb, a_kmajor, b_kmajor, st);
 }
 
@@ -1812,7 +1839,7 @@ extern "C" int shg_gemm_dact(const void* dy, const void* w, void* dx, const void
     if (!dy || !w || !dx || !pre) return fail_arg("gemm_dact: null pointer");
     if (M <= 0 || N <= 0 || K <= 0) return fail_arg("gemm_dact: sizes must be positive");
     if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("gemm_dact: bad dtype");
-    if (act < 0 || act > 2) return fail_arg("gemm_dact: bad activation");
+    if (act < 0 || act > 3 || (act == SHG_ACT_SAVED_GRAD && dtype != SHG_BF16)) return fail_arg("gemm_dact: bad activation");
     if (int e = drop_args_ok(p_drop, seed_state, N)) return e;
     const int epc = dtype == SHG_BF16 ? 8 : 4;
     if (N % 8 || K % epc) return fail_arg("gemm_dact: N must be a multiple of 8 and K of the 16-byte chunk");
@@ -1837,8 +1864,12 @@ extern "C" int shg_gemm_act(const void* a, const void* b, void* c, const float* 
         SHG_REPEAT(((M + 255) / 256) * ((N + 255) / 256) >= 120 ? 16 : 32,
                    shg_gemm_act(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, act, pre, p_drop, seed_state, stream_id, stream));
     if (int e = drop_args_ok(p_drop, seed_state, N)) return e;
+    const int save_grad = (act & SHG_ACT_SAVE_GRAD) ? 1 : 0;
+    act &= ~SHG_ACT_SAVE_GRAD;
+    if (save_grad && (dtype_c != SHG_BF16 || !pre || p_drop > 0.f || N % 8))
+        return fail_arg("gemm_act: SHG_ACT_SAVE_GRAD needs a bf16 output, a `pre` buffer, N % 8 == 0 and no dropout");
     return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 0, act, pre, stream, p_drop,
-                      seed_state, stream_id);
+                      seed_state, stream_id, save_grad);
 }
 
 extern "C" int64_t shg_conv3d_k533_workspace_bytes(int B, int T, int H, int W) {

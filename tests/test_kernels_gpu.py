@@ -787,6 +787,36 @@ def test_gemm_dact_fuses_activation_backward_and_bias_gradient(K, dtype, act):
         assert torch.equal(dx2, dx)
 
 
+def test_gemm_act_can_save_the_activation_derivative_for_gemm_dact(K):
+    """SHG_ACT_SAVE_GRAD / SHG_ACT_SAVED_GRAD (include/shg_vqa.h): the forward epilogue stores gelu'(u) in `pre`, the input-gradient
+    epilogue multiplies by it - against the derivative recomputed from the stored pre-activation (the default pair) and against
+    torch's erf GELU in fp64; same outputs `h` either way."""
+    gen = torch.Generator().manual_seed(77)
+    for (M, N, Kd) in [(12576, 3072, 768), (1280, 3072, 768), (200, 264, 72)]:
+        x = torch.randn(M, Kd, generator=gen).bfloat16().to(DEV)
+        w1 = (torch.randn(N, Kd, generator=gen) / math.sqrt(Kd)).bfloat16().to(DEV)
+        b1 = torch.randn(N, generator=gen).to(DEV)
+        dy = torch.randn(M, 96, generator=gen).bfloat16().to(DEV)
+        w2 = (torch.randn(96, N, generator=gen) / 10).bfloat16().to(DEV)
+        h0, pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        h1, der = torch.empty_like(h0), torch.empty_like(h0)
+        K.gemm_act(x, w1, h0, b1, 1, pre)
+        K.gemm_act(x, w1, h1, b1, 1 | 0x100, der)
+        assert torch.equal(h0, h1)
+        u = (x.double() @ w1.double().t() + b1.double())
+        u.requires_grad_(True)
+        F.gelu(u).sum().backward()
+        assert torch.allclose(der.double(), u.grad, rtol=2 ** -7, atol=2e-3), (der.double() - u.grad).abs().max().item()
+        dx0, dx1 = torch.empty_like(h0), torch.empty_like(h0)
+        db0, db1 = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+        K.gemm_dact(dy, w2, dx0, pre, db0, 1)
+        K.gemm_dact(dy, w2, dx1, der, db1, 3)
+        ref = (dy.double() @ w2.double()) * u.grad
+        _assert_close(dx0, ref, torch.bfloat16, scale=2.0)
+        _assert_close(dx1, ref, torch.bfloat16, scale=2.0)
+        assert torch.allclose(db1.double().cpu(), dx1.double().cpu().sum(0), rtol=1e-4, atol=2e-3 * math.sqrt(M))
+
+
 def test_fast_gelu_of_the_bf16_path_over_its_whole_range(K):
     """bf16 kernels evaluate erf by a rational approximation (|err| <= 1.5e-7): forward and gradient against
     torch's erf GELU on a dense grid including both tails."""

@@ -51,10 +51,11 @@ for (M, N, Kd) in (shapes if __name__ == "__main__" else []):
         res = []
         for side in (0, 1):
             _lib.set_tuning("epilogue_side", side)
-            res.append((bench(lambda: K.gemm(dy, w, dx, None, True, False, accumulate=True)), bench(lambda: K.gemm_dact(dy, w, dx, pre, db, 1))))
+            res.append((bench(lambda: K.gemm(dy, w, dx, None, True, False, accumulate=True)), bench(lambda: K.gemm_dact(dy, w, dx, pre, db, 1)),
+                        bench(lambda: K.gemm_dact(dy, w, dx, pre, db, 3))))
         t_rd = bench(lambda: torch.matmul(dy, w))
-        print("M=%6d N=%5d K=%5d  dgrad (out %d cols, K %d): plain %7.1f us | accumulate %7.1f -> %7.1f us | dact+csum %7.1f -> %7.1f us (loads up front off -> on) | torch.mm %7.1f us"
-              % (M, N, Kd, Kd, N, t_d, res[0][0], res[1][0], res[0][1], res[1][1], t_rd), flush=True)
+        print("M=%6d N=%5d K=%5d  dgrad (out %d cols, K %d): plain %7.1f us | accumulate %7.1f -> %7.1f us | dact+csum %7.1f -> %7.1f us (loads up front off -> on) | with the stored derivative %7.1f us | torch.mm %7.1f us"
+              % (M, N, Kd, Kd, N, t_d, res[0][0], res[1][0], res[0][1], res[1][1], res[1][2], t_rd), flush=True)
         continue
     if os.environ.get("WGRAD_ONLY"):
         print("M=%6d N=%5d K=%5d wgrad %7.1f us %6.0f TF" % (M, N, Kd, t_w, fl / t_w / 1e6), flush=True)
