@@ -42,7 +42,8 @@ enum Tune {
     TUNE_SPLITK_TARGET,        // weight-gradient split-K: workgroups aimed for (384) - "splitk_target"
     TUNE_SPLITK_MIN_STEPS,     // ... and the fewest K steps per split (8) - "splitk_min_steps"
     TUNE_LARGE_MIN_K,          // 256 x 256 tile of the generic kernel from this K (128) - "large_min_k"
-    TUNE_WGRAD_GROUP,          // grouped weight gradients: bit 0 K % 64 == 0 groups, bit 1 ragged K (3) - "wgrad_group"
+    TUNE_WGRAD_GROUP,          // grouped weight gradients: bit 0 K % 64 == 0 groups, bit 1 ragged K, bit 2 launches of at most
+                               // 256 workgroups = one round of the CUs (7) - "wgrad_group"
     TUNE_CONV_WGRAD_REMAINDER, // conv weight gradient: remainder column blocks as a split launch (1) - "conv_wgrad_remainder"
     TUNE_BERTADAM_MODE,        // bit 0: two vectors per lane, 3: four, 1: non-temporal stores of shadow / zeroed gradient too,
                                // 2: no non-temporal accesses (3; isolated at 289 M parameters: 1.575 ms = 6.24 TB/s against

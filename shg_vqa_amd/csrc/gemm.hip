@@ -1470,7 +1470,8 @@ template <typename TC, typename SrcA, typename SrcB> struct G8Entry {
     SrcB sb;
     Epilogue<TC> ep;
     int64_t M, N, K;
-    int grid_m, tiles, split, first;
+    int grid_m, tiles, split, first;      // tiles: tile slots of this entry IN THIS LAUNCH; first: its first block index
+    int tile0, total;                      // ... which are the slots tile0 .. tile0 + tiles - 1 of the problem's `total`
 };
 template <typename TC, typename SrcA, typename SrcB> struct G8Group {
     int n;
@@ -1484,8 +1485,8 @@ __global__ __launch_bounds__(512) void gemm8_group_kernel(G8Group<TC, SrcA, SrcB
     const G8Entry<TC, SrcA, SrcB>& e = grp.e[p];
     const int local = (int)blockIdx.x - e.first;
     if (local >= e.tiles * e.split) return;                    // padding of the range up to a multiple of 8
-    gemm8_body<TC, SrcA, SrcB, false>(e.sa, e.sb, e.ep, e.M, e.N, e.K, e.grid_m, StreamK{nullptr, nullptr, 0, 100}, local % e.tiles,
-                                      local / e.tiles, e.tiles, e.split);
+    gemm8_body<TC, SrcA, SrcB, false>(e.sa, e.sb, e.ep, e.M, e.N, e.K, e.grid_m, StreamK{nullptr, nullptr, 0, 100}, e.tile0 + local % e.tiles,
+                                      local / e.tiles, e.total, e.split);
 }
 
 // Partial-sum slots and flags of the stream-K launches live in a CALLER-OWNED workspace (shg_streamk_workspace_bytes /
@@ -1740,7 +1741,8 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
     hipStream_t st = (hipStream_t)stream;
     using SA = PlainSrc<bf16_t, false>;
     using Grp = G8Group<float, SA, SA>;
-    // SHG_WGRAD_GROUP: bit 0 grouped launches, bit 1 also for row counts that are not a multiple of 64 (ragged last K-tile)
+    // "wgrad_group": bit 0 grouped launches, bit 1 also for row counts that are not a multiple of 64 (ragged last K-tile), bit 2
+    // launches of at most 256 workgroups
     const int mode = (int)tuning(TUNE_WGRAD_GROUP);
     int i = 0;
     while (i < n) {
@@ -1752,42 +1754,75 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
                    q.ldx % 8 == 0 && al16(q.dy) && al16(q.x) && al16(q.gw) && q.n_in % 4 == 0 &&
                    (int64_t)BK * q.ldy * 2 < ((int64_t)1 << 32) && (int64_t)BK * q.ldx * 2 < ((int64_t)1 << 32);
         };
-        while (j < n && j - i < G8_MAX_GROUP && ok8(probs[j])) {
+        while (j < n && ok8(probs[j])) {
             tiles += ((probs[j].n_out + 255) / 256) * ((probs[j].n_in + 255) / 256);
             ++j;
         }
         if (j - i >= 2 && tiles >= 48) {
-            Grp g{};
-            g.n = j - i;
-            int first = 0;
             for (int k = i; k < j; ++k) {
                 const shg_wgrad_problem_t& q = probs[k];
                 if (!q.dy || !q.x || !q.gw || q.rows <= 0 || q.n_out <= 0 || q.n_in <= 0) return fail_arg("wgrad_group: bad problem");
-                G8Entry<float, SA, SA>& e = g.e[k - i];
-                const int64_t gm = (q.n_out + 255) / 256, gn = (q.n_in + 255) / 256, nk = (q.rows + BK - 1) / BK;
-                // split-K only when the whole group cannot fill the chip: partial tiles meet in C through fp32 atomics
-                int split = 1;
-                if (tiles < 160) split = (int)std::max<int64_t>(1, std::min<int64_t>((224 + tiles - 1) / tiles, nk / 12));
-                // a weight applied more than once (the cross layers' shared modules, modeling_capsbert.py:1247-1249) has several
-                // problems adding into ONE gradient inside this grid: those add with atomics
-                bool shared = false;
-                for (int k2 = i; k2 < j; ++k2) shared = shared || (k2 != k && probs[k2].gw == q.gw);
-                e.sa = SA{(const bf16_t*)q.dy, q.ldy, 0, q.n_out, q.rows};
-                e.sb = SA{(const bf16_t*)q.x, q.ldx, 0, q.n_in, q.rows};
-                e.ep = Epilogue<float>{q.gw, q.n_in, nullptr, nullptr, SHG_ACT_NONE, 1, 1, nullptr, (split > 1 || shared) ? 1 : 0};
-                e.M = q.n_out; e.N = q.n_in; e.K = q.rows;
-                e.grid_m = tile_order(gm, gn);
-                e.tiles = (int)(gm * gn);
-                e.split = split;
-                e.first = first;
-                first += (e.tiles * split + 7) / 8 * 8;
             }
             auto kern = gemm8_group_kernel<float, SA, SA>;
             const size_t lds = std::max<size_t>(2 * 8 * Tile64<bf16_t>::BYTES, (size_t)8 * 64 * STG_LD * 4);
             static std::atomic<uint64_t> raised{0};
             raise_lds_limit(raised, reinterpret_cast<const void*>(kern), (int)lds);
-            hipLaunchKernelGGL(kern, dim3((unsigned)first), dim3(512), lds, st, g);
-            if (int e = check_launch("wgrad_group")) return e;
+            // Launches of at most 256 workgroups - ONE round of the 256 CUs: a workgroup owns its CU for a whole contraction
+            // (197 K-tiles = 300 us at 12 576 rows), so a launch of 336 workgroups ran two rounds, the second one a third full
+            // (round 2 packed whatever the executor's queue held: 272-368 workgroups per launch, 718 / 756 us for the relation
+            // layers' two groups).  A problem whose tiles do not fit the current launch continues in the next one (tile0).
+            // Small runs (< 160 tiles in all) stay one launch with the contraction split over gridDim-like slots (atomics).
+            const bool small = tiles < 160 && j - i <= G8_MAX_GROUP;
+            const int cap = (mode & 4) ? 256 : (1 << 20);            // ("wgrad_group" bit 2 off: launches as large as the queue, as in round 2)
+            Grp g{};
+            int used = 0;
+            auto launch = [&]() -> int {
+                if (!g.n) return 0;
+                hipLaunchKernelGGL(kern, dim3((unsigned)used), dim3(512), lds, st, g);
+                g = Grp{};
+                used = 0;
+                return check_launch("wgrad_group");
+            };
+            for (int k = i; k < j; ++k) {
+                const shg_wgrad_problem_t& q = probs[k];
+                const int64_t gm = (q.n_out + 255) / 256, gn = (q.n_in + 255) / 256, nk = (q.rows + BK - 1) / BK;
+                const int total = (int)(gm * gn);
+                int split = 1;
+                if (small) split = (int)std::max<int64_t>(1, std::min<int64_t>((224 + tiles - 1) / tiles, nk / 12));
+                // a weight applied more than once (the cross layers' shared modules, modeling_capsbert.py:1247-1249) has several
+                // problems adding into ONE gradient inside this run: those add with atomics
+                bool shared = false;
+                for (int k2 = i; k2 < j; ++k2) shared = shared || (k2 != k && probs[k2].gw == q.gw);
+                int t0 = 0;
+                while (t0 < total) {
+                    if (g.n == G8_MAX_GROUP || (!small && used >= cap)) {
+                        if (int e = launch()) return e;
+                    }
+                    int c = total - t0;
+                    if (!small) {
+                        const int room = cap - used;                    // (a multiple of 8)
+                        if (c > room) c = room / 8 * 8;                 // an unfinished problem leaves the launch on an 8-boundary
+                        if (c == 0) {
+                            if (int e = launch()) return e;
+                            continue;
+                        }
+                    }
+                    G8Entry<float, SA, SA>& e = g.e[g.n++];
+                    e.sa = SA{(const bf16_t*)q.dy, q.ldy, 0, q.n_out, q.rows};
+                    e.sb = SA{(const bf16_t*)q.x, q.ldx, 0, q.n_in, q.rows};
+                    e.ep = Epilogue<float>{q.gw, q.n_in, nullptr, nullptr, SHG_ACT_NONE, 1, 1, nullptr, (split > 1 || shared) ? 1 : 0};
+                    e.M = q.n_out; e.N = q.n_in; e.K = q.rows;
+                    e.grid_m = tile_order(gm, gn);
+                    e.tiles = c;
+                    e.tile0 = t0;
+                    e.total = total;
+                    e.split = split;
+                    e.first = used;
+                    used += (c * split + 7) / 8 * 8;
+                    t0 += c;
+                }
+            }
+            if (int e = launch()) return e;
             i = j;
             continue;
         }

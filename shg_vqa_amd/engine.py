@@ -73,7 +73,11 @@ class Engine:
         # tiles is pending (SHG_WGRAD_DEFER=0: every weight gradient is its own launch, issued at once)
         self.defer_wgrads = os.environ.get("SHG_WGRAD_DEFER", "1") != "0"
         self.kv_ahead = int(os.environ.get("SHG_KV_AHEAD", "0"))
-        self.wgrad_flush_tiles = int(os.environ.get("SHG_WGRAD_FLUSH_TILES", "224"))
+        # queued weight-gradient tiles (256 x 256) from which a grouped launch goes out: two relation layers are 216 tiles = ONE round
+        # of the 256 CUs; with 224 (round 2) the queue went out at three layers = 324 tiles = two rounds, the second a quarter
+        # full (tools/step_ab.py: 100 / 150 / 180 / 200 / 215 / 224 / 256 / 430 / 512 tiles -> -0.29 / -0.57 / -0.52 / -0.56 / -0.61 / 0 /
+        # -0.16 / -0.19 / +0.12 ms per step)
+        self.wgrad_flush_tiles = int(os.environ.get("SHG_WGRAD_FLUSH_TILES", "200"))
         self.pending_keep, self.pending_params = [], []
         self._exec = None                 # shg_exec_t* of the sub-layer executor (event ring for the weight-gradient stream)
         self._run = None                  # persistent shg_run_t handed to every executor call

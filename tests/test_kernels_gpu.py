@@ -1152,6 +1152,16 @@ def test_wgrad_group_is_exact_on_integer_data_and_handles_mixed_problem_lists(K)
     ref = a[2] + a[0].float().t() @ a[1].float() + b[0].float().t() @ b[1].float()
     K.wgrad_group([a, c, (b[0], b[1], a[2])])
     assert torch.equal(a[2], ref), (a[2] - ref).abs().max()
+    # a queue of three relation layers (3 x 108 tiles): launches of at most 256 workgroups, so problems are cut between launches -
+    # on 8-tile boundaries (the 36-tile feed-forward weights) and at odd tile counts (27-tile fused q/k/v, 9-tile out-projection)
+    layers = []
+    for _ in range(3):
+        layers += [prob(12576, 2304, 768), prob(12576, 768, 768), prob(12576, 3072, 768), prob(12576, 768, 3072)]
+    ref = [gw + dy.float().t() @ x.float() for dy, x, gw in layers]
+    K.wgrad_group(layers)
+    torch.cuda.synchronize()
+    for i, ((dy, x, gw), r) in enumerate(zip(layers, ref)):
+        assert torch.equal(gw, r), (i, (gw - r).abs().max().item())
     # fp32 operands: the fallback path
     f32 = [(dy.float(), x.float(), gw.clone()) for dy, x, gw in probs[:3]]
     ref = [gw + dy.t() @ x for dy, x, gw in f32]

@@ -2,7 +2,8 @@
 `name=value[,name=value...]` given on the command line, blocks of steps are timed in rotation and the mean ms/step printed next to
 the baseline (all switches at their defaults).
 
-    python tools/step_ab.py gemm8_tile_m=0 epilogue_side=0 "attn_nb_dq=2,attn_nb=1" [--steps 10] [--rounds 3]"""
+    python tools/step_ab.py gemm8_tile_m=0 epilogue_side=0 "attn_nb_dq=2,attn_nb=1" py:wgrad_flush_tiles=200 [--steps 10] [--rounds 3]
+(`py:<name>` sets an attribute of the host-side engine instead of a library switch)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,12 +30,26 @@ for i in range(3):
     tr.train_step(batches[i % 4])
 torch.cuda.synchronize()
 cases = [("baseline", {})] + [(s, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in s.split(","))) for s in settings]
-defaults = {k: _lib.get_tuning(k) for _, d in cases for k in d}
+E = engine()
+
+
+def _get(k):                      # "py:<attr>" = an attribute of the engine (host-side switch), else a library tuning switch
+    return getattr(E, k[3:]) if k.startswith("py:") else _lib.get_tuning(k)
+
+
+def _set(k, v):
+    if k.startswith("py:"):
+        setattr(E, k[3:], v)
+    else:
+        _lib.set_tuning(k, v)
+
+
+defaults = {k: _get(k) for _, d in cases for k in d}
 res = {n: [] for n, _ in cases}
 for r in range(rounds):
     for name, d in cases:
         for k, v in defaults.items():
-            _lib.set_tuning(k, d.get(k, v))
+            _set(k, d.get(k, v))
         tr.train_step(batches[0])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -43,7 +58,7 @@ for r in range(rounds):
         torch.cuda.synchronize()
         res[name].append((time.perf_counter() - t0) / steps * 1e3)
 for k, v in defaults.items():
-    _lib.set_tuning(k, v)
+    _set(k, v)
 base = sum(res["baseline"]) / rounds
 for name, _ in cases:
     t = sum(res[name]) / rounds
