@@ -475,6 +475,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && NB == 1 && MASK == SHG_MASK
 // ------------------------------------------------------------------------------------------------
 // backward, dK and dV
 // ------------------------------------------------------------------------------------------------
+template <typename T> constexpr int dkv_stage_bytes() { return 2 * Tile64<T>::BYTES + 512 + 1024; }
+
 template <typename T, int MASK, int NB, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T* __restrict__ d_o,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
@@ -482,8 +484,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                                                            T* __restrict__ dv, int64_t dv_bs, int64_t dv_ss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using TL = Tile64<T>;
-    // two stages of (Q tile, dO tile, lse[64], delta[64])
-    constexpr int STG = 2 * TL::BYTES + 512;
+    // two stages of (Q tile, dO tile, lse[64], delta[64], keep words: per wave and 16-key block 4 query blocks x 4 words = 128 bytes,
+    // 256 bytes per wave = what one 4-byte-per-lane direct-to-LDS instruction writes)
+    constexpr int STG = dkv_stage_bytes<T>();
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
     int kidx[NB], krow[NB];
@@ -508,15 +511,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // dropout: the forward's lane masks (see the head of the file).  This lane's key sits in tile krow >> 6 at (kt, g, r) =
     // ((krow >> 4) & 3, (krow >> 2) & 3, krow & 3): it reads word e = 4 kt + r of every 16-query block and tests bits 16 g + ...
-    int64_t keep_base[NB];
-    int keep_shift[NB];
     const int nq16 = (P.Sq + 15) >> 4;
+    int64_t keep_tile0[2] = {0, 0};                                                // per 16-key block of the wave: + r, + qblk * keep_qstep
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-        keep_base[n] = keep_word0(P, b * P.H + h, 0, krow[n] >> 6) + 4 * ((krow[n] >> 4) & 3) + (krow[n] & 3);
-        keep_shift[n] = 16 * ((krow[n] >> 2) & 3) + 4 * g;
+        const int key0c = min((int)blockIdx.x * (64 * NB) + __builtin_amdgcn_readfirstlane(wave) * (16 * NB) + 16 * n, P.Sk - 1);
+        keep_tile0[n] = keep_word0(P, b * P.H + h, 0, key0c >> 6) + 4 * ((key0c >> 4) & 3);
     }
     const int64_t keep_qstep = (int64_t)((P.Sk + 63) >> 6) * 16;                  // words per 16-query block
+    const int keep_shift = 16 * (li >> 2) + 4 * g;                                 // bit of (query 4 g + r, key li) is keep_shift + r
     const bool active = (int)(blockIdx.x * (64 * NB) + wave_u * (16 * NB)) < P.Sk;       // wave-uniform, see the forward kernel
     const bool key_tail = (int)(blockIdx.x * (64 * NB) + (wave_u + 1) * (16 * NB)) > P.Sk;   // this wave holds keys past Sk
     const TileLaneOffsets<T> qoff = tile_lane_offsets<T>(P.q_ss, tid), doff = tile_lane_offsets<T>(P.H * 64, tid);
@@ -533,6 +536,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
         // per-query statistics: 64 floats each, one 4-byte direct-to-LDS load per lane (waves 0 and 1)
         if (wave_u == 0) load_row64_async(base + 2 * TL::BYTES, lse + stat0, qb, P.Sq, lane);
         if (wave_u == 1) load_row64_async(base + 2 * TL::BYTES + 256, delta + stat0, qb, P.Sq, lane);
+        if (DROP) {
+            // the forward's keep words this wave's 16 keys need for the tile's four 16-query blocks: word (qblk, r) = mask word
+            // e = 4 kt(key block) + r of that block, as two dwords - lanes 0..31: (lane >> 3) = query block, (lane >> 1) & 3 = r
+            // (lanes 32..63: the wave's second key block when NB = 2, a duplicate of the first otherwise)
+            const int l32 = lane & 31;
+            const int qblk = min((qb >> 4) + (l32 >> 3), nq16 - 1);                   // (blocks past Sq: don't-care, p is zeroed)
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(P.keep + keep_tile0[NB == 2 ? (lane >> 5) : 0] + (int64_t)qblk * keep_qstep + ((l32 >> 1) & 3)) + (l32 & 1);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(base + 2 * TL::BYTES + 512 + 256 * wave_u), 4, 0, 0);
+        }
     };
 
     f32x4 acc_k[NB][4], acc_v[NB][4];
@@ -553,75 +565,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
         const float* ldsDelta = ldsLse + 64;
         if (qb + 64 < P.Sq) stage(cur ^ 1, qb + 64);
         if (active) {
-        uint32_t kbits[NB][4];                                // keep bits of (queries 16 qt + 4 g + 0..3, this lane's key) in bits 0..3
-        if (DROP) {
-#pragma unroll
-            for (int n = 0; n < NB; ++n)
-#pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
-                    const int qblk = min((qb >> 4) + qt, nq16 - 1);                 // (blocks past Sq: don't-care, p is zeroed)
-                    const uint64_t w = P.keep[keep_base[n] + qblk * keep_qstep];
-                    kbits[n][qt] = (uint32_t)(w >> keep_shift[n]);
-                }
-        }
-        f32x4 s[NB][4], dp[NB][4];
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            const Frag<T> qf0 = lds_row_frag<T>(ldsQ, 16 * qt + li, 0, g), qf1 = lds_row_frag<T>(ldsQ, 16 * qt + li, 32, g);
-            const Frag<T> df0 = lds_row_frag<T>(ldsD, 16 * qt + li, 0, g), df1 = lds_row_frag<T>(ldsD, 16 * qt + li, 32, g);
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                s[n][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[n][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                mma(s[n][qt], qf0, kf[n][0]);
-                mma(s[n][qt], qf1, kf[n][1]);
-                mma(dp[n][qt], df0, vf[n][0]);
-                mma(dp[n][qt], df1, vf[n][1]);
-            }
-        }
-        // lane: key = li of block n, query = qb + 16 qt + 4 g + r
-        f32x4 l2[4], dlt[4];
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            l2[qt] = *reinterpret_cast<const f32x4*>(ldsLse + 16 * qt + 4 * g) * LOG2E;
-            dlt[qt] = *reinterpret_cast<const f32x4*>(ldsDelta + 16 * qt + 4 * g);
-        }
-        auto elems = [&](auto tail_c) {
+        const char* ldsKeep = ldsQ + 2 * TL::BYTES + 512 + 256 * wave_u;     // [key block n][query block 0..3][r 0..3] 64-bit words of this wave
+        // The 64 queries of the tile are worked in two halves of 32 (sx = the pair of 16-query blocks that forms one contraction
+        // step of the dK / dV products): scores, elementwise part and products of a half are complete before the next half
+        // starts, so only two of the four score / dP blocks are live at a time.  (Register count 196 -> 176-192; forcing the 168
+        // of three waves per SIMD with a launch bound gains where it fits without spills - 131 -> 121 us for dQ + dK/dV at
+        // 393 x 393 without dropout - and loses where it spills: the dropout instantiations 140 -> 139-199 us, the full-mask
+        // one 36 -> 47 us.  No bound.)
+        auto half = [&](auto sx_c, auto tail_c) {
+            constexpr int sx = decltype(sx_c)::value;
             constexpr bool TAIL = decltype(tail_c)::value;     // last query tile, or a key block that reaches past Sk
+            f32x4 s[NB][2], dp[NB][2];
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int qt = 2 * sx + q2;
+                const Frag<T> qf0 = lds_row_frag<T>(ldsQ, 16 * qt + li, 0, g), qf1 = lds_row_frag<T>(ldsQ, 16 * qt + li, 32, g);
+                const Frag<T> df0 = lds_row_frag<T>(ldsD, 16 * qt + li, 0, g), df1 = lds_row_frag<T>(ldsD, 16 * qt + li, 32, g);
 #pragma unroll
-                for (int qt = 0; qt < 4; ++qt) {
+                for (int n = 0; n < NB; ++n) {
+                    s[n][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dp[n][q2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma(s[n][q2], qf0, kf[n][0]);
+                    mma(s[n][q2], qf1, kf[n][1]);
+                    mma(dp[n][q2], df0, vf[n][0]);
+                    mma(dp[n][q2], df1, vf[n][1]);
+                }
+            }
+            // lane: key = li of block n, query = qb + 16 qt + 4 g + r
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int qt = 2 * sx + q2;
+                const f32x4 l2 = *reinterpret_cast<const f32x4*>(ldsLse + 16 * qt + 4 * g) * LOG2E;
+                const f32x4 dlt = *reinterpret_cast<const f32x4*>(ldsDelta + 16 * qt + 4 * g);
+                uint32_t kb4[NB];                              // keep bits of (queries 16 qt + 4 g + 0..3, this lane's key) in bits 0..3
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    kb4[n] = DROP ? (uint32_t)(*reinterpret_cast<const uint64_t*>(ldsKeep + 128 * n + 32 * qt + 8 * (li & 3)) >> keep_shift) : 0u;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int query = qb + 16 * qt + 4 * g + r;
                         float t;
-                        if (MASK == SHG_MASK_KEY) t = fmaf(s[n][qt][r], c2, kmask2[n]);
+                        if (MASK == SHG_MASK_KEY) t = fmaf(s[n][q2][r], c2, kmask2[n]);
                         else if (MASK == SHG_MASK_FULL)
-                            t = fmaf(s[n][qt][r], c2, P.mask[(int64_t)min(query, P.Sq - 1) * P.Sk + krow[n]] * LOG2E);
-                        else t = s[n][qt][r] * c2;
-                        float p = fast_exp2(t - l2[qt][r]);
+                            t = fmaf(s[n][q2][r], c2, P.mask[(int64_t)min(query, P.Sq - 1) * P.Sk + krow[n]] * LOG2E);
+                        else t = s[n][q2][r] * c2;
+                        float p = fast_exp2(t - l2[r]);
                         if (TAIL) p = (query >= P.Sq || kidx[n] >= P.Sk) ? 0.f : p;
-                        float dpe = dp[n][qt][r];
+                        float dpe = dp[n][q2][r];
                         float pd = p;
-                        if (DROP) {
-                            const bool keep = (kbits[n][qt] >> r) & 1u;
-                            dpe = keep ? dpe * P.drop_scale : 0.f;
-                            pd = keep ? p * P.drop_scale : 0.f;
+                        if (DROP) {                              // dS = P_dropped dP - P delta with P_dropped = keep ? P / (1 - p) : 0
+                            pd = ((kb4[n] >> r) & 1u) ? p * P.drop_scale : 0.f;
+                            s[n][q2][r] = fmaf(pd, dpe, -p * dlt[r]);
+                        } else {
+                            s[n][q2][r] = p * (dpe - dlt[r]);
                         }
-                        s[n][qt][r] = p * (dpe - dlt[qt][r]);   // dS
-                        dp[n][qt][r] = pd;                       // dropped P
+                        dp[n][q2][r] = pd;                       // dropped P
                     }
-                }
-        };
-        if (qb + 64 > P.Sq || key_tail) elems(std::true_type{}); else elems(std::false_type{});
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
+            }
             Frag<T> pf[NB], dsf[NB];
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
-                pf[n] = acc_frag<T>(dp[n][2 * sx], dp[n][2 * sx + 1]);
-                dsf[n] = acc_frag<T>(s[n][2 * sx], s[n][2 * sx + 1]);
+                pf[n] = acc_frag<T>(dp[n][0], dp[n][1]);
+                dsf[n] = acc_frag<T>(s[n][0], s[n][1]);
             }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -632,6 +639,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P, const T
                     mma(acc_k[n][d], qc, dsf[n]);
                 }
             }
+        };
+        if (qb + 64 > P.Sq || key_tail) {
+            half(std::integral_constant<int, 0>{}, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            half(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            half(std::integral_constant<int, 0>{}, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            half(std::integral_constant<int, 1>{}, std::false_type{});
         }
         }   // active
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -775,11 +791,11 @@ extern "C" int shg_attention_bwd(const void* q, const void* k, const void* v, co
         const int nb = nb_dkv == 2 ? blocks_per_wave(Sk, dtype) : 1;
         dim3 grid((Sk + 64 * nb - 1) / (64 * nb), H, B);
         if (dtype == SHG_F32)
-            ATTN_DISPATCH(attn_bwd_dkv_kernel, float, 1, 2 * (2 * Tile64<float>::BYTES + 512), P, (const float*)d_o, lse, delta, (float*)dk, dk_bstride, dk_sstride, (float*)dv, dv_bstride, dv_sstride);
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, float, 1, 2 * dkv_stage_bytes<float>(), P, (const float*)d_o, lse, delta, (float*)dk, dk_bstride, dk_sstride, (float*)dv, dv_bstride, dv_sstride);
         else if (nb == 2)
-            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 2, 2 * (2 * Tile64<bf16_t>::BYTES + 512), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 2, 2 * dkv_stage_bytes<bf16_t>(), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
         else
-            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 1, 2 * (2 * Tile64<bf16_t>::BYTES + 512), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
+            ATTN_DISPATCH(attn_bwd_dkv_kernel, bf16_t, 1, 2 * dkv_stage_bytes<bf16_t>(), P, (const bf16_t*)d_o, lse, delta, (bf16_t*)dk, dk_bstride, dk_sstride, (bf16_t*)dv, dv_bstride, dv_sstride);
     }
     return check_launch("attention_bwd");
 }
