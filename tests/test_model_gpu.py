@@ -468,8 +468,14 @@ def test_overlapped_optimizer_update_gives_the_same_parameters():
     (p0, g0, s0), (p1, g1, s1) = res
     assert s0 == s1 == 3
     assert (g0 == 0).all() and (g1 == 0).all()          # the optimiser pass leaves the gradient arena zeroed
-    # fp32 atomics in the split-K weight gradients / column sums make two runs differ in the last bits
-    assert torch.allclose(p0, p1, rtol=0, atol=2e-6), (p0 - p1).abs().max()
+    # fp32 atomics (split-K weight gradients, the bias-gradient column sums of the attention backward kernels, shared weights)
+    # make two runs differ in the last bits of a gradient; BertAdam's m / (sqrt(v) + eps) turns that into an O(1) change of the
+    # update direction where a gradient element is itself ~0 (without bias correction |m / sqrt(v)| reaches 0.1 / sqrt(0.001) = 3.2 in
+    # the first steps), so single elements may differ by up to 2 x 3.2 x the sum of the steps' learning rates (1e-5 x (0 + 0.1 +
+    # 0.2) = 3e-6 here) - but only a vanishing share of the 365 M parameters does
+    d = (p0 - p1).abs()
+    assert d.max().item() <= 2e-5, d.max()
+    assert (d > 2e-7).float().mean().item() < 1e-4, (d > 2e-7).float().mean()
 
 
 def test_whole_step_hipgraph_replay_matches_eager_steps():
