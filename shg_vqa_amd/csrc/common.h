@@ -55,6 +55,11 @@ enum Tune {
                                // leaves idle, the smaller tile's extra CU-time costs 0.4-2 % (three interleaved pairs) - "gemm8_tile_m"
     TUNE_ATTN_BWD_FUSED,       // 1: one backward kernel for dQ / dK / dV where available - "attn_bwd_fused"
     TUNE_EPILOGUE_SIDE,        // 1: GEMM row writers issue the loads of `C +=` / activation-backward forms up front - "epilogue_side"
+    TUNE_CONV_K_ORDER,         // convolutions on the 8-phase kernel.  Bits 0-1, forward / input gradient: n > 0 = K-tiles in blocks of
+                               // 64 * 2^(n-1) channels, all 45 taps of a block before the next (the 45 uses of a 128-byte input line
+                               // fall within 45-180 consecutive K-tiles: L2 hits; conv1 6.27 -> 2.49 GB of L2 misses per launch), 0 =
+                               // storage order (tap-major).  Bit 2, weight gradient: 256-column blocks channel-block-major, so that the
+                               // tiles an XCD runs together gather the same input lines (6) - "conv_k_order"
     TUNE_REPEAT_FAMILY,        // DIAGNOSTIC (0): bit mask of kernel families whose every launch is issued TWICE (all idempotent:
                                // 1 attention forward, 2 attention backward, 4 LayerNorm forward, 8 LayerNorm backward,
                                // 16 non-accumulating GEMMs of >= 120 tiles of 256 x 256, 32 smaller non-accumulating GEMMs,

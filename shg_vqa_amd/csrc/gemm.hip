@@ -60,6 +60,9 @@ __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u
 
 template <typename T, bool KMAJ> struct PlainSrc {
     static constexpr bool KMAJOR = KMAJ;
+    static constexpr bool KPERM = false;
+    static constexpr bool NPERM = false;
+    __device__ __forceinline__ int64_t k_of_tile(int64_t kt) const { return kt * 64; }
     const T* p;
     int64_t ld, r0, R, K;
     // contraction-strided layout: K row (0..63) inside a K-tile that chunk i of this thread holds
@@ -118,8 +121,15 @@ template <typename T, bool KMAJ> struct PlainSrc {
 struct ConvGeom {
     int Cin, Hp, Wp;          // padded input plane
     uint32_t inv_cin;         // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, inv_cin) for k < 2^32 / Cin
+    int kperm;                // 8-phase kernel: visit the K-tiles channel-block-major (all 45 taps of 64 channels, then the next 64)
 };
-static ConvGeom conv_geom(int Cin, int Hp, int Wp) { return ConvGeom{Cin, Hp, Wp, (uint32_t)(0x100000000ull / (uint32_t)Cin) + 1u}; }
+static int conv_k_order(int Cin) {                     // 0: storage order; n: blocks of 64 * 2^(n-1) channels, n <= 3
+    const int n = (int)tuning(TUNE_CONV_K_ORDER) & 3;
+    return (n >= 1 && n <= 3 && Cin % (64 << (n - 1)) == 0) ? n : 0;
+}
+static ConvGeom conv_geom(int Cin, int Hp, int Wp) {
+    return ConvGeom{Cin, Hp, Wp, (uint32_t)(0x100000000ull / (uint32_t)Cin) + 1u, conv_k_order(Cin)};
+}
 // tap < 45 -> (kt, kh, kw) by multiply-shift (exact on that range): the wave-uniform address math of the
 // direct-to-LDS loads sits in the instruction stream of the load phase, where an integer division costs ~30 instructions
 __device__ __forceinline__ int64_t tap_offset(const ConvGeom& g, int tap) {
@@ -131,6 +141,20 @@ __device__ __forceinline__ uint32_t div_cin(const ConvGeom& g, uint32_t k) { ret
 // A operand of the conv forward: rows = output positions (gathered), K = (tap, channel), K contiguous.
 template <typename T, int NTHR> struct ConvRowSrc {
     static constexpr bool KMAJOR = true;
+    // K = (tap, channel) is a sum: its 64-wide tiles may be visited in any order as long as BOTH operands follow it.  Tap-major (the
+    // storage order) re-reads every input line 45 times with a whole sweep over the channels (an XCD's ~10 row panels x Cin x 2 B,
+    // 10 MB at 2 048 channels) between two uses: each of them misses the 4 MB L2.  Channel-block-major (g.kperm) keeps the 45 uses
+    // of a 128-byte line within 45 consecutive K-tiles.
+    static constexpr bool KPERM = true;
+    static constexpr bool NPERM = false;
+    __device__ __forceinline__ int64_t k_of_tile(int64_t kt) const {
+        // blocks of nb = 2^(kperm-1) K-tiles (64 nb channels): tile kt = (block, tap, tile in block).  Branch-free (a branch inside the
+        // 8-phase loop splits its phases into basic blocks the scheduler cannot interleave across: +8-24 % per launch, measured)
+        const uint32_t sh = (uint32_t)max(g.kperm - 1, 0), k = (uint32_t)kt, q = k >> sh, sub = k - (q << sh);
+        const uint32_t blk = (q * 11651u) >> 19, tap = q - blk * 45u;                 // q / 45 for q < 20 000
+        const uint32_t kp = tap * (uint32_t)g.Cin + (((blk << sh) + sub) << 6);
+        return (int64_t)(g.kperm ? kp : k << 6);
+    }
     const T* x;
     const int32_t* pos;       // [M] padded-input position index of output position m (tap 0)
     int64_t r0, M;
@@ -180,6 +204,16 @@ template <typename T, int NTHR> struct ConvColSrc {
     ConvGeom g;
     int32_t posreg[Stage<T>::NCH];      // gather positions of the NEXT K-step, fetched one step ahead
     int64_t cbase = 0;                  // a launch over the column blocks [cbase, cbase + N) of the problem: r0 counts from cbase
+    // 8-phase kernel: the launch's 256-column blocks in channel-block-major order (nblk = Cin / 256 > 0): block L = lblk0 + bn of the
+    // launch is (channel block L / 45, tap L % 45), i.e. columns 256 (tap nblk + channel block) of the problem.  Neighbouring tiles
+    // - the ones an XCD runs at the same time - then gather the SAME input lines shifted by a tap, instead of eight different
+    // 512-byte pieces of every position.
+    static constexpr bool NPERM = true;
+    int nblk = 0, lblk0 = 0;
+    __device__ __forceinline__ int64_t col_of_block(int64_t bn) const {
+        const uint32_t L = (uint32_t)(lblk0 + bn), c = (L * 11651u) >> 19, t = L - c * 45u;
+        return (int64_t)(t * (uint32_t)nblk + c) * 256;
+    }
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void prefetch(int tid, int64_t k0) {
 #pragma unroll
@@ -228,6 +262,7 @@ template <typename T, int NTHR> struct ConvColSrc {
 // transposed weight copy of a textbook conv-transpose is never materialised.
 template <typename T> struct ConvWeightColSrc {
     static constexpr bool KMAJOR = false;
+    static constexpr bool NPERM = false;
     const T* w;
     int64_t r0, R, K;         // R = Cin (columns), K = 45 * Cout
     int Cin, Cout;
@@ -1123,7 +1158,11 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         if (nk <= 0) return false;
     }
     const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
-    const int64_t m0 = bm * TM, n0 = bn * 256;
+    const int64_t m0 = bm * TM;
+    int64_t n0 = bn * 256;
+    if constexpr (SrcB::NPERM) {
+        if (sb.nblk) { n0 = sb.col_of_block(bn); N = sb.R; }     // (the launch's N only counted its column blocks)
+    }
     sa.r0 = m0;
     sb.r0 = n0;
 
@@ -1175,16 +1214,16 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
             // rows 0-63: instruction 0, rows 64-127: instruction 1 (waves 0-3 hold its rows 64-95, waves 4-7 rows 96-127),
             // rows 128-191: instruction 2; half 0 = rows 0-95, half 1 = rows 96-191
             const int whole = h ? 2 : 0;
-            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(whole, (kb + kt) * BK) + offa[whole]), (lds_ptr)(base + NTHR * whole * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(whole, sa.k_of_tile(kb + kt)) + offa[whole]), (lds_ptr)(base + NTHR * whole * 16), 16, 0, 0);
             if ((wave_u >= 4) == (h == 1))
-                __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(1, (kb + kt) * BK) + offa[1]), (lds_ptr)(base + NTHR * 1 * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(1, sa.k_of_tile(kb + kt)) + offa[1]), (lds_ptr)(base + NTHR * 1 * 16), 16, 0, 0);
             return;
         }
         const bool rag = RAGGED_OK && tail && (kb + kt) == nk_all - 1;          // wave-uniform
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * h + ii;
-            const char* src = sa.k_base(i, (kb + kt) * BK) + offa[i];
+            const char* src = sa.k_base(i, sa.k_of_tile(kb + kt)) + offa[i];
             if (rag && ((bad_a >> i) & 1u)) src = reinterpret_cast<const char*>(g_zero16);
             __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
         }
@@ -1196,7 +1235,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * h + ii;
             const uint32_t off = SrcB::DYN ? dyn : offb[i];
-            const char* src = sb.k_base(i, (kb + kt) * BK) + off;
+            const char* src = sb.k_base(i, sa.k_of_tile(kb + kt)) + off;
             if (RAGGED_OK && tail && (kb + kt) == nk_all - 1 && ((bad_b >> i) & 1u)) src = reinterpret_cast<const char*>(g_zero16);
             __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
         }
@@ -1998,6 +2037,7 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
     PlainSrc<bf16_t, false> sa{(const bf16_t*)dy + c0, Cout, 0, cn, Mo};
     if (use_gemm8(cn, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
+        if (Cin % 256 == 0 && (tuning(TUNE_CONV_K_ORDER) & 4)) sb.nblk = Cin / 256;
         // Tile-count quantisation: conv1's 3 x 360 = 1 080 tiles are 4.22 rounds of 256 CUs - the fifth round runs 56
         // workgroups for the full K = 18 816 while 200 CUs idle (0.36 ms of a 2.3 ms launch, the last kernel of backward).
         // The column blocks of the whole rounds go out as one launch; the remaining blocks as a second launch with the
@@ -2017,8 +2057,8 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
                 if (model(sp) < model(split)) split = sp;
             if (gn_a >= 1 && gn_b >= 1 && split >= 2 && model(split) < 0.7 * model(1)) {
                 if (int e = launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_a * 256, Mo, st, "conv3d_k533_wgrad")) return e;
-                sb.cbase = gn_a * 256;
-                ep.c += gn_a * 256;
+                if (sb.nblk) sb.lblk0 = (int)gn_a;
+                else { sb.cbase = gn_a * 256; ep.c += gn_a * 256; }
                 return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_b * 256, Mo, st, "conv3d_k533_wgrad", split);
             }
         }

@@ -3,7 +3,8 @@
 the baseline (all switches at their defaults).
 
     python tools/step_ab.py gemm8_tile_m=0 epilogue_side=0 "attn_nb_dq=2,attn_nb=1" py:wgrad_flush_tiles=200 [--steps 10] [--rounds 3]
-(`py:<name>` sets an attribute of the host-side engine instead of a library switch)"""
+(`py:<name>` sets an attribute of the host-side engine instead of a library switch; `step:overlap_update=1` passes the keyword to
+AGQA.train_step)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -33,12 +34,19 @@ cases = [("baseline", {})] + [(s, dict((kv.split("=")[0], int(kv.split("=")[1]))
 E = engine()
 
 
+step_kw = {}
+
+
 def _get(k):                      # "py:<attr>" = an attribute of the engine (host-side switch), else a library tuning switch
+    if k.startswith("step:"):
+        return 0
     return getattr(E, k[3:]) if k.startswith("py:") else _lib.get_tuning(k)
 
 
 def _set(k, v):
-    if k.startswith("py:"):
+    if k.startswith("step:"):
+        step_kw[k[5:]] = bool(v)
+    elif k.startswith("py:"):
         setattr(E, k[3:], v)
     else:
         _lib.set_tuning(k, v)
@@ -50,11 +58,11 @@ for r in range(rounds):
     for name, d in cases:
         for k, v in defaults.items():
             _set(k, d.get(k, v))
-        tr.train_step(batches[0])
+        tr.train_step(batches[0], **step_kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            tr.train_step(batches[i % 4])
+            tr.train_step(batches[i % 4], **step_kw)
         torch.cuda.synchronize()
         res[name].append((time.perf_counter() - t0) / steps * 1e3)
 for k, v in defaults.items():
