@@ -307,6 +307,13 @@ int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, i
  * all-reduce of the first two thirds runs under the last third instead of behind everything. */
 int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin,
                                 int Cout, int c0, int cn, int accumulate, const void* workspace, void* stream);
+/* OVERWRITE form for a gradient that has exactly one writer per step: rows [c0, c0 + cn) of dw are SET (they need not be zero
+ * beforehand - the optimiser then skips zeroing them, 4 bytes per parameter less in its sweep) and the sum of their squares is
+ * ADDED to *sumsq (fp64, device) - the convolution's share of clip_grad_norm_'s global norm (agqaHGQA.py:391) without a second
+ * pass over 283 MB: on the 8-phase kernel it comes out of the accumulators (whole 256 x 256 tiles), otherwise a pass over the
+ * finished rows follows.  cn a multiple of 8; the fused form needs cn % 256 == 0. */
+int shg_conv3d_k533_wgrad_sumsq(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin,
+                                int Cout, int c0, int cn, double* sumsq, const void* workspace, void* stream);
 int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
                           int Cin, int Cout, const void* workspace, void* stream);
 /* NCDHW fp32 features -> channels-last, spatially zero-padded (dtype) : [B,C,T,H,W] -> [B,T,H+2,W+2,C] */
@@ -325,6 +332,11 @@ int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int
  *   optimizer.zero_grad() of the next step, agqaHGQA.py:387, without a separate sweep over the arena).
  */
 int shg_sumsq(const float* x, int64_t n, double* partial, int n_partial, float* out_norm, void* stream);
+/* the same in two stages, for a norm over several ranges of the arena plus sums other kernels have already accumulated:
+ * shg_sumsq_partial fills partial[0 .. n_partial) for one range (any stream); shg_sumsq_final: out_norm[0] =
+ * sqrt(sum of partial[0 .. n_partial) + (extra ? extra[0] : 0)) and resets extra[0] to 0 for the next step. */
+int shg_sumsq_partial(const float* x, int64_t n, double* partial, int n_partial, void* stream);
+int shg_sumsq_final(const double* partial, int n_partial, double* extra, float* out_norm, void* stream);
 int shg_bertadam_arena(float* param, float* grad, float* m, float* v, void* shadow_bf16, int64_t n,
                        const float* grad_norm, float max_norm, float lr, float warmup, int64_t t_total,
                        float b1, float b2, float eps, float weight_decay, int64_t* step_state, int bump_step,

@@ -55,9 +55,12 @@ _SIGNATURES = {
     "shg_streamk_workspace_init": ([P, P], c_int),
     "shg_conv3d_k533_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, P, P], c_int),
     "shg_conv3d_k533_wgrad_slice": ([P, P, P, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
+    "shg_conv3d_k533_wgrad_sumsq": ([P, P, P, I, I, I, I, I, I, I, I, I, P, P, P], c_int),
     "shg_conv3d_k533_dgrad": ([P, P, P, I, I, I, I, I, I, I, P, P], c_int),
     "shg_ncdhw_to_padded_cl": ([P, P, I, I, I, I, I, I, P], c_int),
     "shg_sumsq": ([P, L, P, I, P, P], c_int),
+    "shg_sumsq_partial": ([P, L, P, I, P], c_int),
+    "shg_sumsq_final": ([P, I, P, P, P], c_int),
     "shg_bertadam_arena": ([P, P, P, P, P, L, P, F, F, F, L, F, F, F, F, P, I, P], c_int),
     "shg_add_i64": ([P, L, P], c_int),
     "shg_cast_f32": ([P, P, I, L, P], c_int),

@@ -60,6 +60,8 @@ enum Tune {
                                // fall within 45-180 consecutive K-tiles: L2 hits; conv1 6.27 -> 2.49 GB of L2 misses per launch), 0 =
                                // storage order (tap-major).  Bit 2, weight gradient: 256-column blocks channel-block-major, so that the
                                // tiles an XCD runs together gather the same input lines (6) - "conv_k_order"
+    TUNE_WGRAD_GROUP_CAP,      // grouped weight gradients: workgroups per launch (256 = one round of the CUs) - "wgrad_group_cap"
+    TUNE_WGRAD_GROUP_SPLIT,    // ... and parts of every problem's contraction (1) - "wgrad_group_split"
     TUNE_REPEAT_FAMILY,        // DIAGNOSTIC (0): bit mask of kernel families whose every launch is issued TWICE (all idempotent:
                                // 1 attention forward, 2 attention backward, 4 LayerNorm forward, 8 LayerNorm backward,
                                // 16 non-accumulating GEMMs of >= 120 tiles of 256 x 256, 32 smaller non-accumulating GEMMs,

@@ -210,10 +210,17 @@ template <typename T, int NTHR> struct ConvColSrc {
     // 512-byte pieces of every position.
     static constexpr bool NPERM = true;
     int nblk = 0, lblk0 = 0;
-    __device__ __forceinline__ int64_t col_of_block(int64_t bn) const {
-        const uint32_t L = (uint32_t)(lblk0 + bn), c = (L * 11651u) >> 19, t = L - c * 45u;
+    __device__ __forceinline__ int64_t col_of_lblock(int64_t lb) const {            // lb: logical block of the whole problem
+        if (!nblk) return lb * 256;
+        const uint32_t L = (uint32_t)lb, c = (L * 11651u) >> 19, t = L - c * 45u;
         return (int64_t)(t * (uint32_t)nblk + c) * 256;
     }
+    __device__ __forceinline__ int64_t col_of_block(int64_t bn) const { return col_of_lblock(lblk0 + bn); }
+    // overwrite mode of the weight gradient (shg_conv3d_k533_wgrad_sumsq): the launch over the whole rounds of column blocks also
+    // zeroes the column blocks [zero_blk0, zero_blk0 + zero_blks) of the `zero_rows` output rows, which the split launch behind it
+    // then adds into with atomics
+    float* zero_base = nullptr;
+    int zero_blk0 = 0, zero_blks = 0, zero_rows = 0;
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void prefetch(int tid, int64_t k0) {
 #pragma unroll
@@ -324,6 +331,7 @@ template <typename TC> struct Epilogue {
     uint64_t stream_id;
     int no_side;              // 1: the row writers' up-front-load forms are switched off ("epilogue_side" tuning switch, A/B runs)
     int save_grad;            // forward: `pre` receives act'(u) instead of u (SHG_ACT_SAVE_GRAD)
+    double* sumsq;            // conv weight gradient on the 8-phase kernel, plain stores of whole tiles: *sumsq += sum of C[m, n]^2
 };
 
 __device__ __forceinline__ float act_grad_rt(float u, int act, bool fast) {
@@ -1161,7 +1169,14 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     const int64_t m0 = bm * TM;
     int64_t n0 = bn * 256;
     if constexpr (SrcB::NPERM) {
-        if (sb.nblk) { n0 = sb.col_of_block(bn); N = sb.R; }     // (the launch's N only counted its column blocks)
+        if (sb.nblk || sb.lblk0) { n0 = sb.col_of_block(bn); N = sb.R; }     // (the launch's N only counted its column blocks)
+        if (sb.zero_base && by == 0) {                           // 1 KB row segments, two per pass of the workgroup
+            const int64_t segs = (int64_t)sb.zero_rows * sb.zero_blks;
+            for (int64_t q = (int64_t)bx * 2 + (tid >> 8); q < segs; q += (int64_t)gx * 2) {
+                const int64_t blk = q / sb.zero_rows, row = q - blk * sb.zero_rows;
+                sb.zero_base[row * sb.R + sb.col_of_lblock(sb.zero_blk0 + blk) + (tid & 255)] = 0.f;
+            }
+        }
     }
     sa.r0 = m0;
     sb.r0 = n0;
@@ -1365,6 +1380,24 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     int tid2 = tid;
     if constexpr (SK) asm volatile("" : "+v"(tid2));
     const int wave2 = tid2 >> 6, lane2 = tid2 & 63, g2 = lane2 >> 4, li2 = lane2 & 15;
+    if constexpr (SrcB::NPERM && !SK) {
+        if (ep.sumsq) {                              // (whole tiles, plain stores: the accumulators ARE the stored values)
+            float ss = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 v = acc[a][b][i][j];
+                            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                        }
+            const double tot = wave_sum_f64((double)ss);
+            if (lane2 == 0) atomicAdd(ep.sumsq, tot);
+        }
+    }
 
     if constexpr (SK) {
         int s_ = seg;
@@ -1812,7 +1845,11 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
             // layers' two groups).  A problem whose tiles do not fit the current launch continues in the next one (tile0).
             // Small runs (< 160 tiles in all) stay one launch with the contraction split over gridDim-like slots (atomics).
             const bool small = tiles < 160 && j - i <= G8_MAX_GROUP;
-            const int cap = (mode & 4) ? 256 : (1 << 20);            // ("wgrad_group" bit 2 off: launches as large as the queue, as in round 2)
+            // ("wgrad_group" bit 2 off: launches as large as the queue, as in round 2; "wgrad_group_cap": fewer than one round, so
+            //  that the dependent chains on the other streams always find free CUs; "wgrad_group_split": contraction of every
+            //  problem in that many parts = shorter-lived workgroups, partial sums added with atomics)
+            const int cap = (mode & 4) ? (int)std::min<int64_t>(256, std::max<int64_t>(64, tuning(TUNE_WGRAD_GROUP_CAP) / 8 * 8)) : (1 << 20);
+            const int force_split = (int)std::min<int64_t>(8, std::max<int64_t>(1, tuning(TUNE_WGRAD_GROUP_SPLIT)));
             Grp g{};
             int used = 0;
             auto launch = [&]() -> int {
@@ -1828,6 +1865,7 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
                 const int total = (int)(gm * gn);
                 int split = 1;
                 if (small) split = (int)std::max<int64_t>(1, std::min<int64_t>((224 + tiles - 1) / tiles, nk / 12));
+                else if (force_split > 1 && nk / force_split >= 12) split = force_split;
                 // a weight applied more than once (the cross layers' shared modules, modeling_capsbert.py:1247-1249) has several
                 // problems adding into ONE gradient inside this run: those add with atomics
                 bool shared = false;
@@ -1839,7 +1877,7 @@ extern "C" int shg_wgrad_group(const shg_wgrad_problem_t* probs, int n, int dtyp
                     }
                     int c = total - t0;
                     if (!small) {
-                        const int room = cap - used;                    // (a multiple of 8)
+                        const int room = (cap - used) / split;          // (a multiple of 8)
                         if (c > room) c = room / 8 * 8;                 // an unfinished problem leaves the launch on an 8-boundary
                         if (c == 0) {
                             if (int e = launch()) return e;
@@ -2015,9 +2053,39 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
     return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);
 }
 
-extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
-                                           int Cin, int Cout, int c0, int cn, int accumulate, const void* workspace, void* stream) {
-    SHG_REPEAT(256, shg_conv3d_k533_wgrad_slice(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, workspace, stream));
+// sum of squares of `blks` 256-column blocks (logical blocks lb0 .. of a [rows, R] fp32 matrix, the weight gradient's column
+// order) / of a contiguous fp32 range, added to *out
+__global__ __launch_bounds__(256) void sumsq_blocks_kernel(const float* __restrict__ w, int64_t R, int rows, int lb0, int blks, int nblk,
+                                                           double* __restrict__ out) {
+    ConvColSrc<bf16_t, 512> m{};
+    m.nblk = nblk;
+    double acc = 0.0;
+    const int64_t segs = (int64_t)rows * blks;
+    for (int64_t q = blockIdx.x; q < segs; q += gridDim.x) {
+        const int64_t blk = q / rows, row = q - blk * rows;
+        const float v = w[row * R + m.col_of_lblock(lb0 + blk) + threadIdx.x];
+        acc += (double)(v * v);
+    }
+    __shared__ double sh[4];
+    acc = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_range_kernel(const float* __restrict__ w, int64_t n, double* __restrict__ out) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)(w[i] * w[i]);
+    __shared__ double sh[4];
+    acc = wave_sum_f64(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// sumsq != null (only with whole 256 x 256 tiles on the 8-phase kernel, conv_wgrad_impl decides): OVERWRITE mode - dw rows
+// [c0, c0 + cn) = the gradient, *sumsq += the sum of their squares out of the accumulators
+static int conv_wgrad_core(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin, int Cout, int c0,
+                           int cn, int accumulate, double* sumsq, const void* workspace, void* stream) {
     if (!x || !dy || !dw) return fail_arg("conv3d_wgrad: null pointer");
     if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
     if (c0 < 0 || cn < 1 || c0 + cn > Cout || c0 % 8 || cn % 8) return fail_arg("conv3d_wgrad: bad output-channel slice (multiples of 8 inside [0, Cout))");
@@ -2045,7 +2113,9 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
         // so that the remainder takes a fraction of a round.  SHG_CONV_WGRAD_REMAINDER=0 switches it off.
         const int rem_on = (int)tuning(TUNE_CONV_WGRAD_REMAINDER);
         const int64_t tiles_m = (cn + 255) / 256, gn = Ncols / 256, total = tiles_m * gn, rounds = total / 256, rem = total % 256;
-        if (rem_on && accumulate && Ncols % 256 == 0 && rounds >= 1 && rem > 0 && Mo / BK >= 16) {
+        const bool fused = sumsq != nullptr;                                  // whole tiles: the accumulators are the stored values
+        if (fused) ep.sumsq = sumsq;
+        if (rem_on && (accumulate || fused) && Ncols % 256 == 0 && rounds >= 1 && rem > 0 && Mo / BK >= 16) {
             const int64_t gn_a = rounds * 256 / tiles_m, gn_b = gn - gn_a, tiles_b = tiles_m * gn_b;
             // split of the remainder launch: the one with the shortest modelled time (rounds of 256 workgroups, each
             // 19 us + 1.52 us per K-tile - the kernel's measured K scan), if that beats one plain round by 30 %
@@ -2056,10 +2126,23 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
             for (int sp = 2; sp <= 8 && nk / sp >= 8.0; ++sp)
                 if (model(sp) < model(split)) split = sp;
             if (gn_a >= 1 && gn_b >= 1 && split >= 2 && model(split) < 0.7 * model(1)) {
+                if (fused) {                 // the first launch zeroes the remainder's blocks, the split launch adds into them
+                    sb.zero_base = ep.c; sb.zero_blk0 = (int)gn_a; sb.zero_blks = (int)gn_b; sb.zero_rows = cn;
+                }
                 if (int e = launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_a * 256, Mo, st, "conv3d_k533_wgrad")) return e;
-                if (sb.nblk) sb.lblk0 = (int)gn_a;
+                sb.zero_base = nullptr;
+                float* const c_rows = ep.c;
+                if (sb.nblk || fused) sb.lblk0 = (int)gn_a;
                 else { sb.cbase = gn_a * 256; ep.c += gn_a * 256; }
-                return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_b * 256, Mo, st, "conv3d_k533_wgrad", split);
+                ep.sumsq = nullptr;
+                ep.accumulate = 1;
+                if (int e = launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_b * 256, Mo, st, "conv3d_k533_wgrad", split)) return e;
+                if (fused) {
+                    hipLaunchKernelGGL(sumsq_blocks_kernel, dim3((unsigned)std::min<int64_t>(1024, cn * gn_b)), dim3(256), 0, st, c_rows, Ncols, cn,
+                                       (int)gn_a, (int)gn_b, sb.nblk, sumsq);
+                    return check_launch("conv3d_k533_wgrad_sumsq");
+                }
+                return 0;
             }
         }
         return launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, Ncols, Mo, st, "conv3d_k533_wgrad");
@@ -2071,6 +2154,41 @@ extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float*
     ConvColSrc<bf16_t, 256> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
     return launch_cfg<bf16_t, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, cn, Ncols, Mo, st, "conv3d_k533_wgrad", false);
 }
+
+// The overwrite form.  Fused where the 8-phase kernel runs whole tiles; elsewhere (fp32 parity mode, small problems, slices that
+// are not multiples of 256 rows) the rows are zeroed, the usual accumulating launch follows - the very arithmetic of the plain
+// scheme, bit for bit - and one pass over the finished rows adds their squares.
+static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin, int Cout, int c0,
+                           int cn, int accumulate, double* sumsq, const void* workspace, void* stream) {
+    if (!sumsq) return conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, nullptr, workspace, stream);
+    if (!x || !dy || !dw) return fail_arg("conv3d_wgrad: null pointer");
+    if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
+    if (c0 < 0 || cn < 1 || c0 + cn > Cout || c0 % 8 || cn % 8) return fail_arg("conv3d_wgrad: bad output-channel slice (multiples of 8 inside [0, Cout))");
+    const int64_t Mo = (int64_t)B * (T - 4) * H * W, Ncols = (int64_t)45 * Cin;
+    const bool fuse = dtype == SHG_BF16 && cn % 256 == 0 && Ncols % 256 == 0 &&
+                      use_gemm8(cn, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2);
+    if (fuse) return conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, sumsq, workspace, stream);
+    float* rows = dw + (int64_t)c0 * Ncols;
+    hipError_t e = hipMemsetAsync(rows, 0, (size_t)cn * Ncols * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return (int)e; }
+    if (int rc = conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 1, nullptr, workspace, stream)) return rc;
+    hipLaunchKernelGGL(sumsq_range_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, rows, (int64_t)cn * Ncols, sumsq);
+    return check_launch("conv3d_k533_wgrad_sumsq");
+}
+
+extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
+                                           int Cin, int Cout, int c0, int cn, int accumulate, const void* workspace, void* stream) {
+    SHG_REPEAT(256, shg_conv3d_k533_wgrad_slice(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, workspace, stream));
+    return conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, nullptr, workspace, stream);
+}
+
+extern "C" int shg_conv3d_k533_wgrad_sumsq(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
+                                           int Cin, int Cout, int c0, int cn, double* sumsq, const void* workspace, void* stream) {
+    if (!sumsq || (reinterpret_cast<uintptr_t>(sumsq) & 7)) return fail_arg("conv3d_wgrad_sumsq: sumsq must be an 8-byte aligned device pointer");
+    SHG_REPEAT(256, conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, nullptr, workspace, stream));
+    return conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, sumsq, workspace, stream);
+}
+
 
 extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                                      int Cin, int Cout, int accumulate, const void* workspace, void* stream) {

@@ -26,9 +26,12 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partial, int n_partial, float* __restrict__ out) {
+// extra: one more addend that kernels have been accumulating with atomics (the convolutions' fused sums); it is reset for the next step
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double* __restrict__ partial, int n_partial, float* __restrict__ out,
+                                                          double* __restrict__ extra = nullptr) {
     __shared__ double sh[256];
     double acc = 0.0;
+    if (extra && threadIdx.x == 0) { acc = extra[0]; extra[0] = 0.0; }
     for (int i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -147,8 +150,24 @@ extern "C" int shg_sumsq(const float* x, int64_t n, double* partial, int n_parti
     if (reinterpret_cast<uintptr_t>(x) & 15) return fail_arg("sumsq: x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(n_partial), dim3(256), 0, st, x, n, partial);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, partial, n_partial, out_norm);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, partial, n_partial, out_norm, (double*)nullptr);
     return check_launch("sumsq");
+}
+
+extern "C" int shg_sumsq_partial(const float* x, int64_t n, double* partial, int n_partial, void* stream) {
+    if (!x || !partial) return fail_arg("sumsq_partial: null pointer");
+    if (n < 0 || n_partial < 1 || n_partial > 65535) return fail_arg("sumsq_partial: bad sizes");
+    if (reinterpret_cast<uintptr_t>(x) & 15) return fail_arg("sumsq_partial: x must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(n_partial), dim3(256), 0, (hipStream_t)stream, x, n, partial);
+    return check_launch("sumsq_partial");
+}
+
+extern "C" int shg_sumsq_final(const double* partial, int n_partial, double* extra, float* out_norm, void* stream) {
+    if (!partial || !out_norm) return fail_arg("sumsq_final: null pointer");
+    if (n_partial < 1 || n_partial > (1 << 20)) return fail_arg("sumsq_final: bad sizes");
+    if (extra && (reinterpret_cast<uintptr_t>(extra) & 7)) return fail_arg("sumsq_final: extra must be 8-byte aligned");
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_partial, out_norm, extra);
+    return check_launch("sumsq_final");
 }
 
 extern "C" int shg_bertadam_arena(float* param, float* grad, float* m, float* v, void* shadow_bf16, int64_t n,

@@ -73,6 +73,9 @@ class Engine:
         # tiles is pending (SHG_WGRAD_DEFER=0: every weight gradient is its own launch, issued at once)
         self.defer_wgrads = os.environ.get("SHG_WGRAD_DEFER", "1") != "0"
         self.kv_ahead = int(os.environ.get("SHG_KV_AHEAD", "0"))
+        # (priority of the branch streams, priority of the weight-gradient stream): SHG_STREAM_PRIO="-1,0" runs the dependent chains
+        # above the weight-gradient backlog (whose 300-us workgroups otherwise hold every CU while a chain kernel waits)
+        self.stream_priority = tuple(int(v) for v in os.environ.get("SHG_STREAM_PRIO", "0,0").split(","))
         # queued weight-gradient tiles (256 x 256) from which a grouped launch goes out: two relation layers are 216 tiles = ONE round
         # of the 256 CUs; with 224 (round 2) the queue went out at three layers = 324 tiles = two rounds, the second a quarter
         # full (tools/step_ab.py: 100 / 150 / 180 / 200 / 215 / 224 / 256 / 430 / 512 tiles -> -0.29 / -0.57 / -0.52 / -0.56 / -0.61 / 0 /
@@ -88,6 +91,15 @@ class Engine:
         self.first_params = None          # the parameters the step reads first (conv1's weight, bias): updated on the main stream
         self.kernel_events = None        # bench.py: list collecting (start, end) events of the dominant kernel
         self.pending_clip = None
+        # Gradients with exactly ONE writer per step that is able to SET them and to add their sum of squares to norm_extra as it
+        # goes (the two convolutions' weights, 58 % of all parameters: shg_conv3d_k533_wgrad_sumsq): the norm's pass skips them
+        # and the optimiser does not zero them.  overwritten: {arena offset: elements} set that way in the current step;
+        # unzeroed: the same of the last optimiser pass - every one of them is either overwritten again or zeroed before
+        # anything accumulates into it or reads it (claim_overwrite / settle_stale_grads).
+        self.fused_conv_norm = os.environ.get("SHG_CONV_NORM_FUSED", "1") != "0"
+        self.norm_extra = None
+        self.overwritten, self.unzeroed = {}, {}
+        self.overwrite_poisoned = False
 
     # ------------------------------------------------------------------ dropout plumbing
     @property
@@ -271,7 +283,7 @@ class Engine:
         if not self.overlap_wgrad or self.device.type != "cuda":
             return None
         if self._wgrad_stream is None:
-            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+            self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=self.stream_priority[1])
         return self._wgrad_stream
 
     def _on_branch_stream(self):
@@ -285,7 +297,7 @@ class Engine:
         if not (self.branch_mask >> i) & 1:
             return None
         if i not in self._aux_streams:
-            self._aux_streams[i] = torch.cuda.Stream(device=self.device)
+            self._aux_streams[i] = torch.cuda.Stream(device=self.device, priority=self.stream_priority[0])
         return self._aux_streams[i]
 
     def bind_streams(self):
@@ -328,6 +340,38 @@ class Engine:
             self.wait_params_ready()
             self.grad_arena.zero_()
             self.grad_dirty = False
+            self.overwritten, self.unzeroed, self.overwrite_poisoned = {}, {}, False
+            if self.norm_extra is not None:
+                self.norm_extra.zero_()
+
+    # ------------------------------------------------------------------ single-writer gradients (fused norm, no zeroing)
+    def norm_scalar(self):
+        if self.norm_extra is None:
+            self.norm_extra = torch.zeros(1, dtype=torch.float64, device=self.device)
+        return self.norm_extra
+
+    def claim_overwrite(self, p):
+        """True: the caller SETS p's gradient now (and adds its sum of squares to norm_scalar()).  False: it accumulates as
+        usual - into a gradient that is zero or holds this step's earlier contribution."""
+        off = p._shg_off
+        ok = (self.fused_conv_norm and self.grad_ready_hook is None and self.device.type == "cuda" and off % 4 == 0
+              and p._shg_numel % 4 == 0 and off not in self.overwritten and not torch.cuda.is_current_stream_capturing())
+        if ok:
+            self.overwritten[off] = p._shg_numel
+            self.unzeroed.pop(off, None)
+            return True
+        if off in self.overwritten:
+            self.overwrite_poisoned = True          # a second writer in this step: the fused sum no longer describes the gradient
+        if self.unzeroed.pop(off, None) is not None:
+            p._shg_grad.zero_()                     # left unzeroed by the last optimiser pass
+        return False
+
+    def settle_stale_grads(self):
+        """Gradients the last optimiser pass left unzeroed and this step has not overwritten hold LAST step's values: zero them."""
+        for off, n in list(self.unzeroed.items()):
+            if off not in self.overwritten:
+                self.grad_arena[off:off + n].zero_()
+        self.unzeroed = {}
 
     def wait_params_ready(self):
         """BertAdam.step may leave the update of everything but the first convolution's weight running on a side

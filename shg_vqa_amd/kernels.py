@@ -517,6 +517,23 @@ def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False, c0=0, cn=None):
     return dw
 
 
+def conv3d_k533_wgrad_sumsq(x_cl, dy, dw, sumsq, c0=0, cn=None):
+    """Overwrite form: dw rows [c0, c0 + cn) = the weight gradient (no zeroed destination needed), sumsq[0] (float64 [1]) += the sum
+    of their squares (shg_conv3d_k533_wgrad_sumsq)."""
+    _dev(x_cl, dy, dw, sumsq)
+    B, T, Hp, Wp, cin = x_cl.shape
+    H, W = Hp - 2, Wp - 2
+    cout = dy.shape[-1]
+    _need(x_cl.is_contiguous() and dy.is_contiguous() and tuple(dy.shape) == (B, T - 4, H, W, cout) and dy.dtype == x_cl.dtype,
+          "dy must be contiguous [B,T-4,H,W,Cout] of x's dtype")
+    _need(tuple(dw.shape) == (cout, 5, 3, 3, cin) and dw.dtype == torch.float32 and dw.is_contiguous(), "dw fp32 [Cout,5,3,3,Cin]")
+    _need(sumsq.dtype == torch.float64 and sumsq.numel() == 1, "sumsq must be float64 [1]")
+    ws = conv_workspace(B, T, H, W, x_cl.device)
+    _lib.call("shg_conv3d_k533_wgrad_sumsq", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
+              int(c0), int(cout - c0 if cn is None else cn), sumsq.data_ptr(), ws.data_ptr(), _stream())
+    return dw
+
+
 def conv3d_k533_dgrad(dy_padded, w_cl):
     """dy_padded [B,To+8,H+2,W+2,Cout] (dy zero-padded by 4 in T, 1 in H/W); w_cl [Cout,5,3,3,Cin] -> dx [B,To+4,H,W,Cin]."""
     _dev(dy_padded, w_cl)
@@ -553,6 +570,29 @@ def grad_norm(flat_grad, partial=None):
         partial = torch.empty(npart, dtype=torch.float64, device=flat_grad.device)
     out = torch.empty(1, dtype=torch.float32, device=flat_grad.device)
     _lib.call("shg_sumsq", flat_grad.data_ptr(), flat_grad.numel(), partial.data_ptr(), npart, out.data_ptr(), _stream())
+    return out
+
+
+def grad_norm_ranges(flat_grad, ranges, extra=None):
+    """L2 norm over the element ranges [(lo, hi), ..] of a flat fp32 arena (lo, hi multiples of 4) plus sqrt-under-the-root of
+    extra[0] (float64 [1], sums other kernels accumulated; reset to 0 by the call) -> fp32 [1]."""
+    _dev(flat_grad, extra)
+    _need(flat_grad.dtype == torch.float32 and flat_grad.is_contiguous() and flat_grad.dim() == 1, "flat fp32 arena")
+    ranges = [(int(a), int(b)) for a, b in ranges if b > a]
+    _need(all(a % 4 == 0 for a, _ in ranges), "range starts must be multiples of 4 elements")
+    _need(extra is None or (extra.dtype == torch.float64 and extra.numel() == 1), "extra must be float64 [1]")
+    total = sum(b - a for a, b in ranges)
+    partial = torch.empty(1024 + len(ranges), dtype=torch.float64, device=flat_grad.device)
+    out = torch.empty(1, dtype=torch.float32, device=flat_grad.device)
+    used = 0
+    for a, b in ranges:
+        npart = max(1, min(1024 - used - (len(ranges) - 1), int(round(1024.0 * (b - a) / max(total, 1)))))
+        _lib.call("shg_sumsq_partial", flat_grad[a:b].data_ptr(), b - a, partial[used:].data_ptr(), npart, _stream())
+        used += npart
+    if used == 0:
+        partial[:1].zero_()
+        used = 1
+    _lib.call("shg_sumsq_final", partial.data_ptr(), used, _p(extra), out.data_ptr(), _stream())
     return out
 
 

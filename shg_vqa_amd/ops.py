@@ -572,19 +572,28 @@ class _VisualConvTokens(torch.autograd.Function):
             _event_done(tm)
         elif inline:
             tm = _event_pair(E, "kernel_events_wgrad")
-            K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
+            _conv_wgrad(E, x_cl, d1, w1)
             _event_done(tm)
             E.grad_written(w1)
-            K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+            _conv_wgrad(E, y1p, d2, w2)
             E.grad_written(w2)
         else:
             with _WgradStream(y1p, d2):
-                K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+                _conv_wgrad(E, y1p, d2, w2)
             E.grad_written(w2)
             with _WgradStream(x_cl, d1):
-                K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True)
+                _conv_wgrad(E, x_cl, d1, w1)
             E.grad_written(w1)
         return None, None, None, None, None, None, None, None, None
+
+
+def _conv_wgrad(E, x, d, w):
+    """The convolution's weight gradient: its only writer in a step SETS it and adds its share of the gradient norm as it goes
+    (Engine.claim_overwrite); otherwise the usual accumulation."""
+    if E.claim_overwrite(w):
+        K.conv3d_k533_wgrad_sumsq(x, d, w._shg_grad, E.norm_scalar())
+    else:
+        K.conv3d_k533_wgrad(x, d, w._shg_grad, accumulate=True)
 
 
 def visual_conv_tokens(feat, w1, b1, w2, b2, cls_token, pe):

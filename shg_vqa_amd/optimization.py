@@ -24,7 +24,20 @@ def clip_grad_norm_(parameters, max_norm):
     BertAdam.step(), which folds the scaling into its update kernel.  Returns the norm (fp32 [1], device)."""
     E = engine()
     E.join_side_streams()                       # weight gradients may still be in flight on the side stream
-    E.pending_clip = (K.grad_norm(E.grad_arena), float(max_norm))
+    E.settle_stale_grads()
+    if E.overwritten and not E.overwrite_poisoned:
+        # the single-writer gradients (conv weights) have added their sums of squares to E.norm_extra already: the pass reads the rest
+        ranges, at = [], 0
+        for off, n in sorted(E.overwritten.items()):
+            ranges.append((at, off))
+            at = off + n
+        ranges.append((at, E.grad_arena.numel()))
+        norm = K.grad_norm_ranges(E.grad_arena, ranges, E.norm_scalar())
+    else:
+        if E.overwritten:
+            E.norm_scalar().zero_()
+        norm = K.grad_norm(E.grad_arena)
+    E.pending_clip = (norm, float(max_norm))
     return E.pending_clip[0]
 
 
@@ -55,16 +68,34 @@ class BertAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         E.join_side_streams()
         E.wait_params_ready()
+        E.settle_stale_grads()
+        if E.overwritten and getattr(E, "pending_clip", None) is None:
+            E.norm_scalar().zero_()             # (a step without clip_grad_norm_: nobody consumed the fused sums)
         norm, max_norm = getattr(E, "pending_clip", None) or (None, 0.0)
         E.pending_clip = None
         n = E.n_active
+        # gradients their single writer SETS in every step (Engine.claim_overwrite) are not zeroed: 4 bytes per parameter less
+        keep = sorted(E.overwritten.items())
+        E.unzeroed, E.overwritten, E.overwrite_poisoned = dict(keep), {}, False
 
         def update(lo, hi, bump):
-            if hi > lo:
+            if hi <= lo:
+                return
+            segs, at = [], lo
+            for off, cnt in keep:
+                a, b = max(off, lo), min(off + cnt, hi)
+                if b > a:
+                    if a > at:
+                        segs.append((at, a, True))
+                    segs.append((a, b, False))
+                    at = b
+            if hi > at:
+                segs.append((at, hi, True))
+            for i, (a, b, zero) in enumerate(segs):
                 # warmup < 0 means "no warm-up" in the reference (schedule still applies); map to the kernel's contract
-                K.bertadam_arena(E.param_arena[lo:hi], E.grad_arena[lo:hi], E.m_arena[lo:hi], E.v_arena[lo:hi],
-                                 E.shadow_arena[lo:hi], norm, max_norm, g["lr"], g["warmup"], g["t_total"], E.step_state,
-                                 g["b1"], g["b2"], g["e"], g["weight_decay"], bump_step=bump, zero_grad=True)
+                K.bertadam_arena(E.param_arena[a:b], E.grad_arena[a:b], E.m_arena[a:b], E.v_arena[a:b],
+                                 E.shadow_arena[a:b], norm, max_norm, g["lr"], g["warmup"], g["t_total"], E.step_state,
+                                 g["b1"], g["b2"], g["e"], g["weight_decay"], bump_step=bump and i == len(segs) - 1, zero_grad=zero)
 
         first = E.first_params
         side = None

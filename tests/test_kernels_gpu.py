@@ -472,6 +472,25 @@ def test_conv3d_k533_fwd_wgrad_vs_torch(K, dtype, B, T, H, W, Cin, Cout):
     assert torch.allclose(dw2, 2 * dw, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_wgrad_overwrite_form_on_the_small_kernels(K, dtype):
+    """shg_conv3d_k533_wgrad_sumsq where the 8-phase kernel is not used (fp32 parity mode, small problems): same gradient as the
+    plain call into a dirty destination, sum of squares by the pass over the finished rows."""
+    B, T, H, W, Cin, Cout = 2, 7, 5, 5, 64, 48
+    gen = torch.Generator().manual_seed(5)
+    x = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=dtype)
+    x[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).to(dtype)
+    dy = torch.randn(B, T - 4, H, W, Cout, generator=gen).to(DEV).to(dtype)
+    ref = torch.zeros(Cout, 5, 3, 3, Cin, device=DEV)
+    K.conv3d_k533_wgrad(x, dy, ref, accumulate=True)          # the plain scheme: accumulate into a zeroed gradient
+    dw = torch.full_like(ref, 11.0)
+    ss = torch.full((1,), 2.5, dtype=torch.float64, device=DEV)
+    K.conv3d_k533_wgrad_sumsq(x, dy, dw, ss, c0=16, cn=32)
+    assert torch.equal(dw[16:], ref[16:]) and bool((dw[:16] == 11.0).all())
+    want = 2.5 + (ref[16:].double() ** 2).sum().item()
+    assert abs(ss.item() - want) <= 1e-6 * want, (ss.item(), want)
+
+
 def test_conv3d_forward_streamk_is_exact_on_integer_data(K):
     """Conv forward on the stream-K split of the 8-phase kernel (gemm.hip: StreamK; every tile's K-tiles are split between a
     head workgroup, which owns the tile, and one or two tail workgroups).  Small-integer data is exact in fp32, so a lost,
@@ -1066,6 +1085,19 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     assert torch.equal(dw.view(Cout, -1)[512:], ref[512:]) and not dw[:512].any()
     K.conv3d_k533_wgrad(xi.bfloat16(), dyi.bfloat16(), dw, c0=0, cn=512)
     assert torch.equal(dw.view(Cout, -1), ref)
+    # overwrite form (the step's single-writer path: no zeroed destination, the sum of squares for clip_grad_norm_ on the way; the
+    # launch over the whole rounds zeroes the remainder's column blocks, which the split launch then adds into)
+    ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+    want = (ref.double() ** 2).sum().item()
+    dw.fill_(7.0)
+    K.conv3d_k533_wgrad_sumsq(xi.bfloat16(), dyi.bfloat16(), dw, ss)
+    assert torch.equal(dw.view(Cout, -1), ref), (dw.view(Cout, -1) - ref).abs().max()
+    assert abs(ss.item() - want) <= 1e-6 * want, (ss.item(), want)
+    dw.fill_(-3.0)
+    K.conv3d_k533_wgrad_sumsq(xi.bfloat16(), dyi.bfloat16(), dw, ss, c0=512, cn=256)
+    K.conv3d_k533_wgrad_sumsq(xi.bfloat16(), dyi.bfloat16(), dw, ss, c0=0, cn=512)
+    assert torch.equal(dw.view(Cout, -1), ref)
+    assert abs(ss.item() - 2 * want) <= 2e-6 * want, (ss.item(), 2 * want)
     del ref, xi, dyi
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
     xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()

@@ -467,7 +467,12 @@ def test_overlapped_optimizer_update_gives_the_same_parameters():
         res.append((engine().param_arena.clone(), engine().grad_arena.clone(), int(engine().step_state.item())))
     (p0, g0, s0), (p1, g1, s1) = res
     assert s0 == s1 == 3
-    assert (g0 == 0).all() and (g1 == 0).all()          # the optimiser pass leaves the gradient arena zeroed
+    # the optimiser pass leaves the gradient arena zeroed - but for the gradients their single writer SETS in every step (the conv
+    # weights, Engine.claim_overwrite)
+    for off, n in engine().unzeroed.items():
+        g0[off:off + n] = 0
+        g1[off:off + n] = 0
+    assert (g0 == 0).all() and (g1 == 0).all()
     # fp32 atomics (split-K weight gradients, the bias-gradient column sums of the attention backward kernels, shared weights)
     # make two runs differ in the last bits of a gradient; BertAdam's m / (sqrt(v) + eps) turns that into an O(1) change of the
     # update direction where a gradient element is itself ~0 (without bias correction |m / sqrt(v)| reaches 0.1 / sqrt(0.001) = 3.2 in
@@ -476,6 +481,71 @@ def test_overlapped_optimizer_update_gives_the_same_parameters():
     d = (p0 - p1).abs()
     assert d.max().item() <= 2e-5, d.max()
     assert (d > 2e-7).float().mean().item() < 1e-4, (d > 2e-7).float().mean()
+
+
+def test_single_writer_gradients_give_the_same_norm_and_parameters():
+    """The conv weights' gradients are SET by their one writer, which adds their share of the gradient norm on the way; the norm's
+    pass skips them and BertAdam does not zero them (Engine.claim_overwrite, shg_conv3d_k533_wgrad_sumsq).  Against the plain
+    scheme (accumulate into a zeroed arena, one pass over all of it): the norm equals a full pass over the very same gradients
+    in every step; after the first step the conv weights' moments are bit-identical; three steps end at the same parameters."""
+    from shg_vqa_amd.engine import engine
+    from oracle import shg_ref
+    import shg_vqa_amd.agqa_hgqa as trainer_mod
+    from shg_vqa_amd import kernels as KK
+    cfg = shg_ref.Cfg()
+    real_clip = trainer_mod.clip_grad_norm_
+    same_grads = []
+
+    def checked_clip(params, max_norm):
+        e = engine()
+        e.join_side_streams()
+        full = float(KK.grad_norm(e.grad_arena))           # one pass over the whole arena, on the very same gradients
+        out = real_clip(params, max_norm)
+        same_grads.append((float(out), full))
+        return out
+
+    res = []
+    for fused in (False, True):
+        tr = _build(torch.bfloat16)
+        e = engine()
+        e.fused_conv_norm = fused
+        batches = [_device_batch(shg_ref.synthetic_batch(2, cfg, seed=70 + i)) for i in range(3)]
+        for m in tr.model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        trainer_mod.clip_grad_norm_ = checked_clip
+        try:
+            norms, first = [], None
+            for b in batches:
+                norms.append(float(tr.train_step(b)["grad_norm"]))
+                if first is None:
+                    torch.cuda.synchronize()
+                    convs = [p for n, p in tr.model.named_parameters() if p.dim() == 5]
+                    assert len(convs) == 2
+                    first = [(e.m_arena[p._shg_off:p._shg_off + p._shg_numel].clone(), e.v_arena[p._shg_off:p._shg_off + p._shg_numel].clone())
+                             for p in convs]
+                    assert sorted(e.unzeroed) == (sorted(p._shg_off for p in convs) if fused else [])
+        finally:
+            trainer_mod.clip_grad_norm_ = real_clip
+        torch.cuda.synchronize()
+        if fused:
+            assert float(e.norm_scalar()) == 0.0              # consumed and reset by the norm's last kernel
+        res.append((e.param_arena.clone(), norms, first))
+    (p0, n0, f0), (p1, n1, f1) = res
+    assert len(same_grads) == 6
+    for got, full in same_grads:
+        assert abs(got - full) <= 2e-6 * full, same_grads
+    for (m0, v0), (m1, v1) in zip(f0, f1):                    # same gradients, same clip factor, same update - bit for bit
+        assert torch.equal(m0, m1) and torch.equal(v0, v1)
+    # (later steps: two RUNS drift apart through the fp32 atomics of other kernels' bias gradients, as in the test above)
+    for a, b in zip(n0, n1):
+        assert abs(a - b) <= 2e-3 * abs(a), (n0, n1)
+    assert (p0 - p1).abs().max().item() <= 2e-5
+    # and a step that does NOT write the conv gradients afterwards must not see last step's values
+    e = engine()
+    assert e.unzeroed
+    e.settle_stale_grads()
+    assert not e.unzeroed and float(e.grad_arena.abs().max()) == 0.0
 
 
 def test_whole_step_hipgraph_replay_matches_eager_steps():

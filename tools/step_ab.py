@@ -27,6 +27,11 @@ model = AGQAModel(171, num_queries=128, num_classes=456, num_actions=157, args=a
 model.to_engine(torch.bfloat16)
 tr = AGQA(args, train_tuple=DataTuple(SyntheticAGQA(n=1), [None] * 1000, None), model=model, t_total=10000)
 batches = bench.synthetic_device_batches(4, 32, 1234, dev)
+if os.environ.get("SHG_MAIN_PRIO"):                       # the whole step on a stream of this priority (with SHG_STREAM_PRIO)
+    print("priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "?")
+    _main = torch.cuda.Stream(device=dev, priority=int(os.environ["SHG_MAIN_PRIO"]))
+    _main.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(_main)
 for i in range(3):
     tr.train_step(batches[i % 4])
 torch.cuda.synchronize()
