@@ -316,6 +316,25 @@ int shg_conv3d_k533_wgrad_sumsq(const void* x, const void* dy, float* dw, int dt
                                 int Cout, int c0, int cn, double* sumsq, const void* workspace, void* stream);
 int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
                           int Cin, int Cout, const void* workspace, void* stream);
+/* Row orders (round 3).  The gather tables make the order of the GEMM rows (output positions) a free choice; row_order 1 is
+ * POSITION-MAJOR: row = ((h W + w) B + b) To + to instead of ((b To + to) H + h) W + w.  With B To a multiple of 64 every
+ * spatial position then owns whole K-tiles of the weight gradient's contraction, and a tile (one kernel tap) skips the positions
+ * where its tap reads the zero border (Conv3d padding (0, 1, 1), modeling_capsbert.py:560-566: 18 % of the products of a 3 x 3
+ * window on a 7 x 7 grid are with zeros) - same sums, bit for bit, in fewer K-tiles.
+ *   shg_conv3d_k533_workspace_bytes_ex / _prepare_ex: tables for a row order; order 1 appends a third table after the two of
+ *     order 0 (each ((M * 4 + 255) / 256) * 256 bytes): std2row[m] = position-major row of standard row m.
+ *   shg_conv3d_k533_fwd takes either workspace (its dense outputs y_pre / y then have that row order; pad_out output is a layout,
+ *     not an order).  shg_conv3d_k533_dgrad_rows: row m of dx is written at dx_rows[m] (the NEXT layer's std2row: its input
+ *     gradient arrives in the order its weight gradient contracts over); NULL = shg_conv3d_k533_dgrad.
+ *   shg_conv3d_k533_wgrad_ex: the general weight gradient - slice [c0, c0 + cn), accumulate or overwrite, optional fused sum of
+ *     squares (only with accumulate = 0), row order of x's table / dy's rows. */
+int64_t shg_conv3d_k533_workspace_bytes_ex(int B, int T, int H, int W, int row_order);
+int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, int W, int row_order, void* stream);
+int shg_conv3d_k533_dgrad_rows(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
+                               int Cin, int Cout, const int32_t* dx_rows, const void* workspace, void* stream);
+int shg_conv3d_k533_wgrad_ex(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin,
+                             int Cout, int c0, int cn, int accumulate, double* sumsq, int row_order, const void* workspace,
+                             void* stream);
 /* NCDHW fp32 features -> channels-last, spatially zero-padded (dtype) : [B,C,T,H,W] -> [B,T,H+2,W+2,C] */
 int shg_ncdhw_to_padded_cl(const float* x, void* y, int dtype, int B, int C, int T, int H, int W, void* stream);
 

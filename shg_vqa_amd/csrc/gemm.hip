@@ -221,6 +221,29 @@ template <typename T, int NTHR> struct ConvColSrc {
     // then adds into with atomics
     float* zero_base = nullptr;
     int zero_blk0 = 0, zero_blks = 0, zero_rows = 0;
+    // Rows (the contraction index) in POSITION-MAJOR order (row = ((h W + w) B + b) To + t, shg_conv3d_k533_prepare_ex order 1) with
+    // tpp = B To / 64 whole K-tiles per spatial position: a tap that reaches into the zero border for position (h, w) gathers only
+    // zeros there, so a tile (one tap) contracts over the nh x nw positions its tap stays inside for and skips the rest - 4 of 9
+    // (kh, kw) taps lose a row and a column of the 7 x 7 grid, 4 lose one: 18 % of the products of a padded 3 x 3 window on 7 x 7
+    // are with zeros.  The remaining terms are summed in the same order: bit-identical results.
+    int tpp = 0, tpp_magic = 0, Hin = 0, Win = 0;          // tpp == 0: every K-tile (any row order)
+    int nw_ = 1, nw_magic = (1 << 20) + 1, h_lo = 0, w_lo = 0;      // per tile, set_tap(); magics: x / d == (x * ((1 << 20) / d + 1)) >> 20 for x < 4 095
+    __device__ __forceinline__ int set_tap(int tap) {       // -> K-tiles of a tile of this tap
+        const int kt3 = (tap * 57) >> 9, r = tap - 9 * kt3, kh = (r * 11) >> 5, kw = r - 3 * kh;
+        const int nh = Hin - (kh != 1 ? 1 : 0);
+        nw_ = Win - (kw != 1 ? 1 : 0);
+        nw_magic = (1 << 20) / nw_ + 1;
+        h_lo = kh == 0 ? 1 : 0;
+        w_lo = kw == 0 ? 1 : 0;
+        return nh * nw_ * tpp;
+    }
+    __device__ __forceinline__ int64_t k_of_tile(int64_t kt) const {       // kt: index into the tile's list of K-tiles -> row offset
+        if (!tpp) return kt * 64;
+        const uint32_t k = (uint32_t)kt, q = (k * (uint32_t)tpp_magic) >> 20, sub = k - q * (uint32_t)tpp;     // position in the list, tile in it
+        const uint32_t hh = (q * (uint32_t)nw_magic) >> 20, ww = q - hh * (uint32_t)nw_;
+        const uint32_t pos_i = ((uint32_t)h_lo + hh) * (uint32_t)Win + (uint32_t)w_lo + ww;
+        return (int64_t)((pos_i * (uint32_t)tpp + sub) << 6);
+    }
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void prefetch(int tid, int64_t k0) {
 #pragma unroll
@@ -1159,10 +1182,17 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     } else {
         const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = bx % 8;
         tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + bx / 8;
+        int64_t nk_tile = nk_all;
+        if constexpr (SrcB::NPERM) {                 // conv weight gradient in position-major row order: only the K-tiles its tap stays inside for
+            if (sb.tpp) {
+                const int64_t bn_ = grid_m < 0 ? tile / gm_t : tile % gn_t;
+                nk_tile = sb.set_tap((int)((uint32_t)sb.col_of_block(bn_) / (uint32_t)sb.g.Cin));
+            }
+        }
         // K range of this workgroup (gridDim.y > 1: split-K, partial sums added with atomics by the epilogue)
-        const int64_t per_split = (nk_all + gy - 1) / gy;
+        const int64_t per_split = (nk_tile + gy - 1) / gy;
         kb = (int64_t)by * per_split;
-        nk = min(nk_all, kb + per_split) - kb;               // K-tiles of this workgroup, numbered 0 .. nk-1 below
+        nk = min(nk_tile, kb + per_split) - kb;              // K-tiles of this workgroup, numbered 0 .. nk-1 below
         if (nk <= 0) return false;
     }
     const int64_t bm = grid_m < 0 ? tile % gm_t : tile / gn_t, bn = grid_m < 0 ? tile / gm_t : tile % gn_t;
@@ -1190,11 +1220,17 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     // gathered B operand (conv weight gradient): one position per thread and K-tile, fetched three K-tiles ahead
     // with a load the compiler does not track (it would drain the direct-to-LDS prefetch at the first use) and
     // retired by the kernel's own counted wait
+    // K-tile number (of this tile's list) -> offset along the contraction index: the convolution sources may permute (forward /
+    // input gradient: channel-block-major) or skip (weight gradient: zero-border positions of the tile's tap)
+    auto kof = [&](int64_t kt_abs) -> int64_t {
+        if constexpr (SrcB::NPERM) return sb.k_of_tile(kt_abs);
+        else return sa.k_of_tile(kt_abs);
+    };
     int32_t dpos[3] = {0, 0, 0}, dnext = 0;
     uint32_t dyn_cur = 0;
     if constexpr (SrcB::DYN) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) dpos[u] = *sb.dyn_ptr(tid, (kb + u) * BK);
+        for (int u = 0; u < 3; ++u) dpos[u] = *sb.dyn_ptr(tid, kof(kb + u));
     }
 
     f32x4 acc[2][2][NI][2];                          // [A half][B half][16-row block][16-col block]
@@ -1229,16 +1265,16 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
             // rows 0-63: instruction 0, rows 64-127: instruction 1 (waves 0-3 hold its rows 64-95, waves 4-7 rows 96-127),
             // rows 128-191: instruction 2; half 0 = rows 0-95, half 1 = rows 96-191
             const int whole = h ? 2 : 0;
-            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(whole, sa.k_of_tile(kb + kt)) + offa[whole]), (lds_ptr)(base + NTHR * whole * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(whole, kof(kb + kt)) + offa[whole]), (lds_ptr)(base + NTHR * whole * 16), 16, 0, 0);
             if ((wave_u >= 4) == (h == 1))
-                __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(1, sa.k_of_tile(kb + kt)) + offa[1]), (lds_ptr)(base + NTHR * 1 * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr)(sa.k_base(1, kof(kb + kt)) + offa[1]), (lds_ptr)(base + NTHR * 1 * 16), 16, 0, 0);
             return;
         }
         const bool rag = RAGGED_OK && tail && (kb + kt) == nk_all - 1;          // wave-uniform
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * h + ii;
-            const char* src = sa.k_base(i, sa.k_of_tile(kb + kt)) + offa[i];
+            const char* src = sa.k_base(i, kof(kb + kt)) + offa[i];
             if (rag && ((bad_a >> i) & 1u)) src = reinterpret_cast<const char*>(g_zero16);
             __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
         }
@@ -1250,7 +1286,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         for (int ii = 0; ii < 2; ++ii) {
             const int i = 2 * h + ii;
             const uint32_t off = SrcB::DYN ? dyn : offb[i];
-            const char* src = sb.k_base(i, sa.k_of_tile(kb + kt)) + off;
+            const char* src = sb.k_base(i, kof(kb + kt)) + off;
             if (RAGGED_OK && tail && (kb + kt) == nk_all - 1 && ((bad_b >> i) & 1u)) src = reinterpret_cast<const char*>(g_zero16);
             __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + NTHR * i * 16), 16, 0, 0);
         }
@@ -1318,7 +1354,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         // ---- phase 1: quadrant (A0, B0)
         if constexpr (SrcB::DYN) {
             if (kt + 3 < nk)
-                asm volatile("global_load_dword %0, %1, off" : "=v"(dnext) : "v"(sb.dyn_ptr(tid, (kb + kt + 3) * BK)) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dnext) : "v"(sb.dyn_ptr(tid, kof(kb + kt + 3))) : "memory");
         }
         SHG_G8_RB(0, fb0)
         __builtin_amdgcn_sched_barrier(0);
@@ -1732,6 +1768,21 @@ __global__ void conv_pos_kernel(int32_t* pos_in, int32_t* pos_out, int B, int Ti
     pos_out[m] = (int32_t)((((int64_t)b * To + to) * Hp + h + 1) * Wp + w + 1);
 }
 
+// Row order 1 (position-major): row r = ((h W + w) B + b) To + to.  Same tables for that order, plus std2row[m] = r for the
+// standard row m = ((b To + to) H + h) W + w (a producer that computes rows in standard order - the next convolution's input
+// gradient - writes them where this order expects them).
+__global__ void conv_pos_grouped_kernel(int32_t* pos_in, int32_t* pos_out, int32_t* std2row, int B, int Tin, int To, int H, int W) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t M = (int64_t)B * To * H * W;
+    if (m >= M) return;
+    const int w = (int)(m % W), h = (int)((m / W) % H), to = (int)((m / ((int64_t)W * H)) % To), b = (int)(m / ((int64_t)W * H * To));
+    const int Hp = H + 2, Wp = W + 2;
+    const int64_t r = (((int64_t)h * W + w) * B + b) * To + to;
+    pos_in[r] = (int32_t)((((int64_t)b * Tin + to) * Hp + h) * Wp + w);
+    pos_out[r] = (int32_t)((((int64_t)b * To + to) * Hp + h + 1) * Wp + w + 1);
+    std2row[m] = (int32_t)r;
+}
+
 // [B,C,T,H,W] fp32 -> [B,T,H+2,W+2,C] (T) with a zero border.  LDS-tiled transpose: a block moves a
 // 64(c) x 64(hw-chunk) tile so that both the reads (along hw) and the writes (along c) are coalesced.
 template <typename T>
@@ -2008,6 +2059,24 @@ extern "C" int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int
     return check_launch("conv3d_prepare");
 }
 
+extern "C" int64_t shg_conv3d_k533_workspace_bytes_ex(int B, int T, int H, int W, int row_order) {
+    const int64_t two = shg_conv3d_k533_workspace_bytes(B, T, H, W);
+    if (two < 0 || row_order < 0 || row_order > 1) return -1;
+    return row_order ? two / 2 * 3 : two;
+}
+
+extern "C" int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, int W, int row_order, void* stream) {
+    if (row_order == 0) return shg_conv3d_k533_prepare(workspace, B, T, H, W, stream);
+    if (!workspace || B < 1 || T < 5 || H < 1 || W < 1 || row_order != 1) return fail_arg("conv3d_prepare_ex: bad argument");
+    const int64_t M = (int64_t)B * (T - 4) * H * W, seg = shg_conv3d_k533_workspace_bytes(B, T, H, W) / 2;
+    int32_t* pos_in = (int32_t*)workspace;
+    int32_t* pos_out = (int32_t*)((char*)workspace + seg);
+    int32_t* std2row = (int32_t*)((char*)workspace + 2 * seg);
+    hipLaunchKernelGGL(conv_pos_grouped_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_in, pos_out, std2row, B,
+                       T, T - 4, H, W);
+    return check_launch("conv3d_prepare_ex");
+}
+
 extern "C" int64_t shg_streamk_workspace_bytes(void) {
     return (int64_t)(STREAMK_FLAG_BYTES + STREAMK_SLOTS * STREAMK_SLOT * sizeof(float));
 }
@@ -2085,7 +2154,7 @@ __global__ __launch_bounds__(256) void sumsq_range_kernel(const float* __restric
 // sumsq != null (only with whole 256 x 256 tiles on the 8-phase kernel, conv_wgrad_impl decides): OVERWRITE mode - dw rows
 // [c0, c0 + cn) = the gradient, *sumsq += the sum of their squares out of the accumulators
 static int conv_wgrad_core(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin, int Cout, int c0,
-                           int cn, int accumulate, double* sumsq, const void* workspace, void* stream) {
+                           int cn, int accumulate, double* sumsq, int row_order, const void* workspace, void* stream) {
     if (!x || !dy || !dw) return fail_arg("conv3d_wgrad: null pointer");
     if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
     if (c0 < 0 || cn < 1 || c0 + cn > Cout || c0 % 8 || cn % 8) return fail_arg("conv3d_wgrad: bad output-channel slice (multiples of 8 inside [0, Cout))");
@@ -2106,6 +2175,13 @@ static int conv_wgrad_core(const void* x, const void* dy, float* dw, int dtype, 
     if (use_gemm8(cn, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2)) {
         ConvColSrc<bf16_t, 512> sb{(const bf16_t*)x, pos_in, 0, Ncols, Mo, g};
         if (Cin % 256 == 0 && (tuning(TUNE_CONV_K_ORDER) & 4)) sb.nblk = Cin / 256;
+        // position-major rows, whole K-tiles per position: skip the positions where the tile's tap reads the zero border
+        if (row_order == 1 && Cin % 256 == 0 && H >= 2 && W >= 2 && ((int64_t)B * (T - 4)) % BK == 0 && Mo / BK < 4000 && (tuning(TUNE_CONV_K_ORDER) & 8)) {
+            sb.tpp = (int)((int64_t)B * (T - 4) / BK);
+            sb.tpp_magic = (1 << 20) / sb.tpp + 1;
+            sb.Hin = H;
+            sb.Win = W;
+        }
         // Tile-count quantisation: conv1's 3 x 360 = 1 080 tiles are 4.22 rounds of 256 CUs - the fifth round runs 56
         // workgroups for the full K = 18 816 while 200 CUs idle (0.36 ms of a 2.3 ms launch, the last kernel of backward).
         // The column blocks of the whole rounds go out as one launch; the remaining blocks as a second launch with the
@@ -2159,19 +2235,20 @@ static int conv_wgrad_core(const void* x, const void* dy, float* dw, int dtype, 
 // are not multiples of 256 rows) the rows are zeroed, the usual accumulating launch follows - the very arithmetic of the plain
 // scheme, bit for bit - and one pass over the finished rows adds their squares.
 static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin, int Cout, int c0,
-                           int cn, int accumulate, double* sumsq, const void* workspace, void* stream) {
-    if (!sumsq) return conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, nullptr, workspace, stream);
+                           int cn, int accumulate, double* sumsq, int row_order, const void* workspace, void* stream) {
+    if (row_order < 0 || row_order > 1) return fail_arg("conv3d_wgrad: row_order must be 0 (standard) or 1 (position-major)");
+    if (!sumsq) return conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, nullptr, row_order, workspace, stream);
     if (!x || !dy || !dw) return fail_arg("conv3d_wgrad: null pointer");
     if (int e = conv_check(dtype, B, T, H, W, Cin, Cout, workspace)) return e;
     if (c0 < 0 || cn < 1 || c0 + cn > Cout || c0 % 8 || cn % 8) return fail_arg("conv3d_wgrad: bad output-channel slice (multiples of 8 inside [0, Cout))");
     const int64_t Mo = (int64_t)B * (T - 4) * H * W, Ncols = (int64_t)45 * Cin;
     const bool fuse = dtype == SHG_BF16 && cn % 256 == 0 && Ncols % 256 == 0 &&
                       use_gemm8(cn, Ncols, Mo, (int64_t)64 * Cout * 2, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2);
-    if (fuse) return conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, sumsq, workspace, stream);
+    if (fuse) return conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, sumsq, row_order, workspace, stream);
     float* rows = dw + (int64_t)c0 * Ncols;
     hipError_t e = hipMemsetAsync(rows, 0, (size_t)cn * Ncols * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return (int)e; }
-    if (int rc = conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 1, nullptr, workspace, stream)) return rc;
+    if (int rc = conv_wgrad_core(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 1, nullptr, row_order, workspace, stream)) return rc;
     hipLaunchKernelGGL(sumsq_range_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, rows, (int64_t)cn * Ncols, sumsq);
     return check_launch("conv3d_k533_wgrad_sumsq");
 }
@@ -2179,14 +2256,23 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw, int dtype, 
 extern "C" int shg_conv3d_k533_wgrad_slice(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                                            int Cin, int Cout, int c0, int cn, int accumulate, const void* workspace, void* stream) {
     SHG_REPEAT(256, shg_conv3d_k533_wgrad_slice(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, workspace, stream));
-    return conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, nullptr, workspace, stream);
+    return conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, nullptr, 0, workspace, stream);
+}
+
+extern "C" int shg_conv3d_k533_wgrad_ex(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin,
+                                        int Cout, int c0, int cn, int accumulate, double* sumsq, int row_order, const void* workspace,
+                                        void* stream) {
+    if (sumsq && (reinterpret_cast<uintptr_t>(sumsq) & 7)) return fail_arg("conv3d_wgrad_ex: sumsq must be 8-byte aligned");
+    if (sumsq && accumulate) return fail_arg("conv3d_wgrad_ex: the sum of squares comes with the overwrite form (accumulate = 0)");
+    SHG_REPEAT(256, conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, nullptr, row_order, workspace, stream));
+    return conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, accumulate, sumsq, row_order, workspace, stream);
 }
 
 extern "C" int shg_conv3d_k533_wgrad_sumsq(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W,
                                            int Cin, int Cout, int c0, int cn, double* sumsq, const void* workspace, void* stream) {
     if (!sumsq || (reinterpret_cast<uintptr_t>(sumsq) & 7)) return fail_arg("conv3d_wgrad_sumsq: sumsq must be an 8-byte aligned device pointer");
-    SHG_REPEAT(256, conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, nullptr, workspace, stream));
-    return conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, sumsq, workspace, stream);
+    SHG_REPEAT(256, conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, nullptr, 0, workspace, stream));
+    return conv_wgrad_impl(x, dy, dw, dtype, B, T, H, W, Cin, Cout, c0, cn, 0, sumsq, 0, workspace, stream);
 }
 
 
@@ -2197,7 +2283,12 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
 
 extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
                                      int Cin, int Cout, const void* workspace, void* stream) {
-    SHG_REPEAT(512, shg_conv3d_k533_dgrad(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, workspace, stream));
+    return shg_conv3d_k533_dgrad_rows(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, nullptr, workspace, stream);
+}
+
+extern "C" int shg_conv3d_k533_dgrad_rows(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
+                                          int Cin, int Cout, const int32_t* dx_rows, const void* workspace, void* stream) {
+    SHG_REPEAT(512, shg_conv3d_k533_dgrad_rows(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, dx_rows, workspace, stream));
     // dx[b,t,h,w,ci] = sum_{tap',co} dYp[b, t+kt', h+kh', w+kw', co] * W[co][44-tap'][ci]; dYp = dy padded by
     // 4 in T and 1 in H/W, so this is the forward gather over dYp with the weight read "contraction strided".
     if (!dy_padded || !w || !dx) return fail_arg("conv3d_dgrad: null pointer");
@@ -2211,11 +2302,11 @@ extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void*
     if (dtype == SHG_F32) {
         ConvRowSrc<float, 256> sa{(const float*)dy_padded, pos_in, 0, M, g};
         ConvWeightColSrc<float> sb{(const float*)w, 0, N, K, Cin, Cout, (uint32_t)(0x100000000ull / (uint32_t)Cout) + 1u};
-        Epilogue<float> ep{(float*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
+        Epilogue<float> ep{(float*)dx, Cin, nullptr, dx_rows, SHG_ACT_NONE, 0, 1, nullptr, 0};
         return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad", false);
     }
     ConvWeightColSrc<bf16_t> sb{(const bf16_t*)w, 0, N, K, Cin, Cout, (uint32_t)(0x100000000ull / (uint32_t)Cout) + 1u};
-    Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, nullptr, SHG_ACT_NONE, 0, 1, nullptr, 0};
+    Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, dx_rows, SHG_ACT_NONE, 0, 1, nullptr, 0};
     if (Cout % 64 == 0 && use_gemm8(M, N, K, (int64_t)B * Tp * (H + 2) * (W + 2) * Cout * 2, (int64_t)64 * 45 * Cin * 2)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
         return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");

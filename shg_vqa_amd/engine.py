@@ -97,6 +97,9 @@ class Engine:
         # unzeroed: the same of the last optimiser pass - every one of them is either overwritten again or zeroed before
         # anything accumulates into it or reads it (claim_overwrite / settle_stale_grads).
         self.fused_conv_norm = os.environ.get("SHG_CONV_NORM_FUSED", "1") != "0"
+        # row order of the first convolution's GEMM rows (ops.conv1_forward and its backward): 1 = position-major, with which the
+        # weight gradient skips the zero-border positions of every tap (include/shg_vqa.h, shg_conv3d_k533_wgrad_ex)
+        self.conv1_row_order = int(os.environ.get("SHG_CONV1_ROW_ORDER", "1"))
         self.norm_extra = None
         self.overwritten, self.unzeroed = {}, {}
         self.overwrite_poisoned = False

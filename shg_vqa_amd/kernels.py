@@ -440,17 +440,25 @@ def wgrad_group(problems):
 _conv_ws = {}
 
 
-def conv_workspace(B, T, H, W, device):
-    """Gather tables of the (5,3,3) conv for one input shape (built once, cached)."""
-    key = (B, T, H, W, str(device))
+def conv_workspace(B, T, H, W, device, order=0):
+    """Gather tables of the (5,3,3) conv for one input shape and row order (0: standard, 1: position-major, include/shg_vqa.h;
+    built once, cached)."""
+    key = (B, T, H, W, str(device), int(order))
     ws = _conv_ws.get(key)
     if ws is None:
-        nbytes = _lib.lib().shg_conv3d_k533_workspace_bytes(B, T, H, W)
-        _need(nbytes > 0, "bad conv shape")
+        nbytes = _lib.lib().shg_conv3d_k533_workspace_bytes_ex(B, T, H, W, int(order))
+        _need(nbytes > 0, "bad conv shape / row order")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _lib.call("shg_conv3d_k533_prepare", ws.data_ptr(), B, T, H, W, _stream())
+        _lib.call("shg_conv3d_k533_prepare_ex", ws.data_ptr(), B, T, H, W, int(order), _stream())
         _conv_ws[key] = ws
     return ws
+
+
+def conv_row_table(B, T, H, W, device):
+    """int32 [B (T-4) H W]: position-major row of every standard row (the third table of the order-1 workspace)."""
+    ws = conv_workspace(B, T, H, W, device, 1)
+    seg = ws.numel() // 3
+    return ws[2 * seg:].view(torch.int32)[:B * (T - 4) * H * W]
 
 
 _streamk_ws = {}
@@ -472,7 +480,7 @@ def streamk_workspace(device):
     return ws
 
 
-def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None):
+def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None, order=0):
     """x_cl [B,T,H+2,W+2,Cin] (zero border); w_cl [Cout,5,3,3,Cin]; -> y [B,T-4,H,W,Cout]
     (or written into the interior of a zero-bordered [B,T-4,H+2,W+2,Cout] buffer when pad_out)."""
     _dev(x_cl, w_cl, bias, out)
@@ -482,7 +490,7 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, wan
     cout = w_cl.shape[0]
     _need(tuple(w_cl.shape) == (cout, 5, 3, 3, cin) and w_cl.dtype == x_cl.dtype, "weight must be [Cout,5,3,3,Cin] of x's dtype")
     _f32vec(bias, cout, "bias")
-    ws = conv_workspace(B, T, H, W, x_cl.device)
+    ws = conv_workspace(B, T, H, W, x_cl.device, order)     # (order 1: the dense outputs - pre, out without pad_out - have position-major rows)
     if out is None:
         shape = (B, T - 4, Hp, Wp, cout) if pad_out else (B, T - 4, H, W, cout)
         out = (torch.zeros if pad_out else torch.empty)(shape, dtype=x_cl.dtype, device=x_cl.device)
@@ -497,9 +505,9 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, wan
     return (out, pre) if want_pre else out
 
 
-def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False, c0=0, cn=None):
+def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False, c0=0, cn=None, order=0):
     """dw [Cout,5,3,3,Cin] fp32 (+)= sum over positions of dy [B,T-4,H,W,Cout] x gathered x_cl; c0 / cn: only the output
-    channels [c0, c0 + cn) (rows of dw)."""
+    channels [c0, c0 + cn) (rows of dw); order: row order of dy's B (T-4) H W rows (1 = position-major)."""
     _dev(x_cl, dy, dw)
     B, T, Hp, Wp, cin = x_cl.shape
     H, W = Hp - 2, Wp - 2
@@ -507,8 +515,11 @@ def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False, c0=0, cn=None):
     _need(x_cl.is_contiguous() and dy.is_contiguous() and tuple(dy.shape) == (B, T - 4, H, W, cout) and dy.dtype == x_cl.dtype,
           "dy must be contiguous [B,T-4,H,W,Cout] of x's dtype")
     _need(tuple(dw.shape) == (cout, 5, 3, 3, cin) and dw.dtype == torch.float32 and dw.is_contiguous(), "dw fp32 [Cout,5,3,3,Cin]")
-    ws = conv_workspace(B, T, H, W, x_cl.device)
-    if c0 == 0 and (cn is None or cn == cout):
+    ws = conv_workspace(B, T, H, W, x_cl.device, order)
+    if order:
+        _lib.call("shg_conv3d_k533_wgrad_ex", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
+                  int(c0), int(cout - c0 if cn is None else cn), 1 if accumulate else 0, None, int(order), ws.data_ptr(), _stream())
+    elif c0 == 0 and (cn is None or cn == cout):
         _lib.call("shg_conv3d_k533_wgrad", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
                   1 if accumulate else 0, ws.data_ptr(), _stream())
     else:
@@ -517,7 +528,7 @@ def conv3d_k533_wgrad(x_cl, dy, dw, accumulate=False, c0=0, cn=None):
     return dw
 
 
-def conv3d_k533_wgrad_sumsq(x_cl, dy, dw, sumsq, c0=0, cn=None):
+def conv3d_k533_wgrad_sumsq(x_cl, dy, dw, sumsq, c0=0, cn=None, order=0):
     """Overwrite form: dw rows [c0, c0 + cn) = the weight gradient (no zeroed destination needed), sumsq[0] (float64 [1]) += the sum
     of their squares (shg_conv3d_k533_wgrad_sumsq)."""
     _dev(x_cl, dy, dw, sumsq)
@@ -528,15 +539,20 @@ def conv3d_k533_wgrad_sumsq(x_cl, dy, dw, sumsq, c0=0, cn=None):
           "dy must be contiguous [B,T-4,H,W,Cout] of x's dtype")
     _need(tuple(dw.shape) == (cout, 5, 3, 3, cin) and dw.dtype == torch.float32 and dw.is_contiguous(), "dw fp32 [Cout,5,3,3,Cin]")
     _need(sumsq.dtype == torch.float64 and sumsq.numel() == 1, "sumsq must be float64 [1]")
-    ws = conv_workspace(B, T, H, W, x_cl.device)
-    _lib.call("shg_conv3d_k533_wgrad_sumsq", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
-              int(c0), int(cout - c0 if cn is None else cn), sumsq.data_ptr(), ws.data_ptr(), _stream())
+    ws = conv_workspace(B, T, H, W, x_cl.device, order)
+    if order:
+        _lib.call("shg_conv3d_k533_wgrad_ex", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
+                  int(c0), int(cout - c0 if cn is None else cn), 0, sumsq.data_ptr(), int(order), ws.data_ptr(), _stream())
+    else:
+        _lib.call("shg_conv3d_k533_wgrad_sumsq", x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), _dt(x_cl), B, T, H, W, cin, cout,
+                  int(c0), int(cout - c0 if cn is None else cn), sumsq.data_ptr(), ws.data_ptr(), _stream())
     return dw
 
 
-def conv3d_k533_dgrad(dy_padded, w_cl):
-    """dy_padded [B,To+8,H+2,W+2,Cout] (dy zero-padded by 4 in T, 1 in H/W); w_cl [Cout,5,3,3,Cin] -> dx [B,To+4,H,W,Cin]."""
-    _dev(dy_padded, w_cl)
+def conv3d_k533_dgrad(dy_padded, w_cl, out_rows=None):
+    """dy_padded [B,To+8,H+2,W+2,Cout] (dy zero-padded by 4 in T, 1 in H/W); w_cl [Cout,5,3,3,Cin] -> dx [B,To+4,H,W,Cin];
+    out_rows (int32 [B (To+4) H W], e.g. conv_row_table of the layer below): row m of dx goes to row out_rows[m]."""
+    _dev(dy_padded, w_cl, out_rows)
     _need(dy_padded.dim() == 5 and dy_padded.is_contiguous() and w_cl.is_contiguous(), "contiguous channels-last tensors")
     B, Tp, Hp, Wp, cout = dy_padded.shape
     H, W = Hp - 2, Wp - 2
@@ -544,8 +560,10 @@ def conv3d_k533_dgrad(dy_padded, w_cl):
     _need(tuple(w_cl.shape) == (cout, 5, 3, 3, cin) and w_cl.dtype == dy_padded.dtype, "weight must be [Cout,5,3,3,Cin] of dy's dtype")
     ws = conv_workspace(B, Tp, H, W, dy_padded.device)
     dx = torch.empty((B, Tp - 4, H, W, cin), dtype=dy_padded.dtype, device=dy_padded.device)
-    _lib.call("shg_conv3d_k533_dgrad", dy_padded.data_ptr(), w_cl.data_ptr(), dx.data_ptr(), _dt(dy_padded), B, Tp, H, W, cin,
-              cout, ws.data_ptr(), _stream())
+    if out_rows is not None:
+        _need(out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() == B * (Tp - 4) * H * W, "out_rows must be int32 [rows of dx]")
+    _lib.call("shg_conv3d_k533_dgrad_rows", dy_padded.data_ptr(), w_cl.data_ptr(), dx.data_ptr(), _dt(dy_padded), B, Tp, H, W, cin,
+              cout, _p(out_rows), ws.data_ptr(), _stream())
     return dx
 
 

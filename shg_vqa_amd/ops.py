@@ -443,12 +443,15 @@ def conv1_forward(feat, w1, b1, bufs=None):
         x_cl[:, :, 1:-1, 1:-1].copy_(feat)                 # the zero border stays as allocated
     else:
         K.ncdhw_to_padded_cl(feat.float().contiguous(), cdt, out=x_cl)
-    K.conv_workspace(B, T, H, W, feat.device)
+    K.conv_workspace(B, T, H, W, feat.device, E.conv1_row_order)
     evs = getattr(E, "kernel_events", None)
     if evs is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    K.conv3d_k533_fwd(x_cl, E.operand(w1), b1._shg_store, ACT_GELU, pad_out=True, out=y1p, want_pre=True, pre_out=pre1)
+    # (E.conv1_row_order = 1: GEMM rows position-major - pre1 and everything backward derives from it have that row order, y1p is a
+    #  layout and does not change; the weight gradient then skips the zero-border positions of every tap)
+    K.conv3d_k533_fwd(x_cl, E.operand(w1), b1._shg_store, ACT_GELU, pad_out=True, out=y1p, want_pre=True, pre_out=pre1,
+                      order=E.conv1_row_order)
     if evs is not None:
         e1.record()
         evs.append((e0, e1))
@@ -548,7 +551,9 @@ class _VisualConvTokens(torch.autograd.Function):
         # of backward), so the side stream's conv2 wgrad waits for it instead of sharing the CUs with it.
         if not fused:
             d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
-        d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2))
+        order1 = E.conv1_row_order
+        rows1 = K.conv_row_table(B, x_cl.shape[1], x_cl.shape[2] - 2, x_cl.shape[3] - 2, x_cl.device) if order1 else None
+        d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2), out_rows=rows1)           # in the row order of pre1 / conv1's weight gradient
         # The conv weight gradients are the last kernels of backward and fill the chip.  They stay on THIS stream:
         # behind the weight-gradient stream's backlog of small split-K GEMMs (it runs ~2 ms late at this point)
         # they would start only when that has drained; here the backlog drains beside them instead.
@@ -567,12 +572,12 @@ class _VisualConvTokens(torch.autograd.Function):
             parts = [(0, cut), (cut, cout - cut)] if 0 < cut < cout else [(0, cout)]
             tm = _event_pair(E, "kernel_events_wgrad")
             for c0, cn in parts:
-                K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True, c0=c0, cn=cn)
+                K.conv3d_k533_wgrad(x_cl, d1, w1._shg_grad, accumulate=True, c0=c0, cn=cn, order=order1)
                 E.grad_written(w1, c0 * per, cn * per)
             _event_done(tm)
         elif inline:
             tm = _event_pair(E, "kernel_events_wgrad")
-            _conv_wgrad(E, x_cl, d1, w1)
+            _conv_wgrad(E, x_cl, d1, w1, order1)
             _event_done(tm)
             E.grad_written(w1)
             _conv_wgrad(E, y1p, d2, w2)
@@ -582,18 +587,18 @@ class _VisualConvTokens(torch.autograd.Function):
                 _conv_wgrad(E, y1p, d2, w2)
             E.grad_written(w2)
             with _WgradStream(x_cl, d1):
-                _conv_wgrad(E, x_cl, d1, w1)
+                _conv_wgrad(E, x_cl, d1, w1, order1)
             E.grad_written(w1)
         return None, None, None, None, None, None, None, None, None
 
 
-def _conv_wgrad(E, x, d, w):
+def _conv_wgrad(E, x, d, w, order=0):
     """The convolution's weight gradient: its only writer in a step SETS it and adds its share of the gradient norm as it goes
-    (Engine.claim_overwrite); otherwise the usual accumulation."""
+    (Engine.claim_overwrite); otherwise the usual accumulation.  order: row order of d (and of x's gather table)."""
     if E.claim_overwrite(w):
-        K.conv3d_k533_wgrad_sumsq(x, d, w._shg_grad, E.norm_scalar())
+        K.conv3d_k533_wgrad_sumsq(x, d, w._shg_grad, E.norm_scalar(), order=order)
     else:
-        K.conv3d_k533_wgrad(x, d, w._shg_grad, accumulate=True)
+        K.conv3d_k533_wgrad(x, d, w._shg_grad, accumulate=True, order=order)
 
 
 def visual_conv_tokens(feat, w1, b1, w2, b2, cls_token, pe):

@@ -1067,6 +1067,7 @@ def test_conv_forward_at_bench_shape_streamk_integer_exact_and_bf16_rows(K, name
 def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     """Weight gradients of both convolutions at B = 32 (conv1: 3 x 360 tiles of 256 x 256, K = 18 816 rows): integer data equal
     to dY^T . im2col(X) in fp32; random bf16 data against the same fp32 product, 64 sampled output channels."""
+    from shg_vqa_amd import _lib
     B, H, W, Cout = 32, 7, 7, 768
     To = T - 4
     gen = torch.Generator().manual_seed(23 + Cin)
@@ -1098,7 +1099,28 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     K.conv3d_k533_wgrad_sumsq(xi.bfloat16(), dyi.bfloat16(), dw, ss, c0=0, cn=512)
     assert torch.equal(dw.view(Cout, -1), ref)
     assert abs(ss.item() - 2 * want) <= 2e-6 * want, (ss.item(), 2 * want)
-    del ref, xi, dyi
+    # position-major rows (shg_conv3d_k533_wgrad_ex, row_order 1): B To = 384 / 256 rows = whole K-tiles per spatial position, every
+    # tile skips the positions where its tap reads the zero border - same integers
+    tbl = K.conv_row_table(B, T, H, W, DEV).long()
+    dy_pm = torch.empty(B * To * H * W, Cout, device=DEV)
+    dy_pm[tbl] = dyi.view(-1, Cout)
+    dy_pm = dy_pm.view(B, To, H, W, Cout).bfloat16()
+    for skip in (14, 6):                                  # with and without the skipping (bit 3 of conv_k_order)
+        _lib.set_tuning("conv_k_order", skip)
+        try:
+            dw.fill_(5.0)
+            K.conv3d_k533_wgrad(xi.bfloat16(), dy_pm, dw, order=1)
+            assert torch.equal(dw.view(Cout, -1), ref), (skip, (dw.view(Cout, -1) - ref).abs().max())
+            K.conv3d_k533_wgrad(xi.bfloat16(), dy_pm, dw, accumulate=True, order=1)
+            assert torch.equal(dw.view(Cout, -1), 2 * ref), skip
+            ss.zero_()
+            dw.fill_(-1.0)
+            K.conv3d_k533_wgrad_sumsq(xi.bfloat16(), dy_pm, dw, ss, order=1)
+            assert torch.equal(dw.view(Cout, -1), ref), skip
+            assert abs(ss.item() - want) <= 1e-6 * want, (skip, ss.item(), want)
+        finally:
+            _lib.set_tuning("conv_k_order", 14)
+    del ref, xi, dyi, dy_pm
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
     xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
     dyr = torch.randn(B, To, H, W, Cout, generator=gen).to(DEV).bfloat16()
@@ -1108,6 +1130,37 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     err = (dw.view(Cout, -1)[ch] - ref).abs().max().item()
     print("%s wgrad B=32: max |dW - ref| = %.3e (|ref| max %.1f)" % (name, err, ref.abs().max().item()))
     assert err <= 2e-4 * ref.abs().max().item() + 1e-3          # fp32 accumulation order only
+
+
+def test_conv_row_order_position_major_forward_and_input_gradient(K):
+    """Row order 1 of the convolution GEMMs (include/shg_vqa.h): the forward's dense pre-activation comes out in position-major
+    rows (same values, the padded output is a layout and does not change), shg_conv3d_k533_dgrad_rows scatters its rows by a table."""
+    B, T, H, W, Cin, Cout = 4, 9, 7, 7, 256, 128
+    To = T - 4
+    gen = torch.Generator().manual_seed(77)
+    x = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
+    x[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
+    w = (torch.randn(Cout, 5, 3, 3, Cin, generator=gen) * 0.05).to(DEV).bfloat16()
+    b = torch.randn(Cout, generator=gen).to(DEV)
+    tbl = K.conv_row_table(B, T, H, W, DEV).long()
+    m = torch.arange(B * To * H * W, device=DEV)
+    w_, h_, t_, b_ = m % W, (m // W) % H, (m // (W * H)) % To, m // (W * H * To)
+    assert torch.equal(tbl, ((h_ * W + w_) * B + b_) * To + t_)
+    y0, pre0 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=True, want_pre=True)
+    y1, pre1 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=True, want_pre=True, order=1)
+    assert torch.equal(y0, y1)
+    assert torch.equal(pre1.view(-1, Cout)[tbl], pre0.view(-1, Cout))
+    d0 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=False)
+    d1 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=False, order=1)
+    assert torch.equal(d1.view(-1, Cout)[tbl], d0.view(-1, Cout))
+    # input gradient of a following conv whose output grid is this one: rows scattered into position-major order
+    dyp = torch.zeros(B, To + 4, H + 2, W + 2, Cout, device=DEV, dtype=torch.bfloat16)
+    dyp[:, 4:To, 1:-1, 1:-1] = torch.randn(B, To - 4, H, W, Cout, generator=gen).to(DEV).bfloat16()
+    w2 = (torch.randn(Cout, 5, 3, 3, Cout, generator=gen) * 0.05).to(DEV).bfloat16()
+    tbl2 = K.conv_row_table(B, To + 4, H, W, DEV)          # the grid of dx: [B, To, H, W]
+    dx0 = K.conv3d_k533_dgrad(dyp, w2)
+    dx1 = K.conv3d_k533_dgrad(dyp, w2, out_rows=tbl2)
+    assert torch.equal(dx1.view(-1, Cout)[tbl2.long()], dx0.view(-1, Cout))
 
 
 def test_conv2_dgrad_at_bench_shape_integer_exact_and_bf16(K):

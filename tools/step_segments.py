@@ -1,7 +1,7 @@
 """Where does the step's wall time go on the MAIN stream?  Events at segment boundaries (forward: module hooks;
 backward: gradient hooks on the tensors between the segments), read after the step; no profiler, so the host runs at
 full speed and side-stream overlap is as in the benchmark."""
-import os, sys
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
@@ -31,7 +31,7 @@ marks = []
 def mark(name):
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()                       # on the current stream of the calling thread
-    marks.append((name, ev))
+    marks.append((name, ev, time.perf_counter()))
 
 
 enc = model.lxrt_encoder.model.bert.encoder
@@ -77,15 +77,21 @@ for it in range(N):                 # back-to-back, as in bench.py: the host run
     mark("step end (optimizer issued)")
     all_marks.append(list(marks))
 torch.cuda.synchronize()
-for ms in all_marks[2:]:
-    t0 = ms[0][1]
-    seq = sorted(((t0.elapsed_time(ev), name) for name, ev in ms[1:]))
+# host column: when the host ISSUED the boundary, on the clock of the step's first event (all steps are timed against the first
+# timed step's start on both clocks).  device - host = how far the host runs ahead there; where that lead is ~0 the device waits
+# for the host.
+ev0, h0 = all_marks[2][0][1], all_marks[2][0][2]
+for k, ms in enumerate(all_marks[2:]):
+    t0, hh0 = ms[0][1], ms[0][2]
+    seq = sorted(((t0.elapsed_time(ev), name, (h - hh0) * 1e3, ev0.elapsed_time(ev) - (h - h0) * 1e3) for name, ev, h in ms[1:]))
     prev = 0.0
-    for t, name in seq:
-        tot.setdefault(name, [0.0, 0.0])
+    for t, name, h, lead in seq:
+        tot.setdefault(name, [0.0, 0.0, 0.0, 1e9])
         tot[name][0] += t / (N - 2)
         tot[name][1] += (t - prev) / (N - 2)
+        tot[name][2] += h / (N - 2)
+        tot[name][3] = min(tot[name][3], lead)
         prev = t
-print("%-62s %9s %9s" % ("boundary (main stream)", "at ms", "segment"))
-for name, (t, d) in sorted(tot.items(), key=lambda kv: kv[1][0]):
-    print("%-62s %9.2f %9.2f" % (name, t, d))
+print("%-62s %9s %9s %12s %16s" % ("boundary (main stream)", "at ms", "segment", "issued at ms", "min device lag"))
+for name, (t, d, h, lead) in sorted(tot.items(), key=lambda kv: kv[1][0]):
+    print("%-62s %9.2f %9.2f %12.2f %16.2f" % (name, t, d, h, lead))
