@@ -328,6 +328,11 @@ int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dt
  *     gradient arrives in the order its weight gradient contracts over); NULL = shg_conv3d_k533_dgrad.
  *   shg_conv3d_k533_wgrad_ex: the general weight gradient - slice [c0, c0 + cn), accumulate or overwrite, optional fused sum of
  *     squares (only with accumulate = 0), row order of x's table / dy's rows. */
+/* shg_conv3d_k533_fwd whose pre-activation row m is written at row pre_rows[m] (NULL: row m): a forward in standard row order
+ * (the faster one: neighbouring rows share input lines) that leaves y_pre in the order the backward works in. */
+int shg_conv3d_k533_fwd_rows(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T, int H,
+                             int W, int Cin, int Cout, int act, int pad_out, void* y_pre, const int32_t* pre_rows,
+                             const void* workspace, void* streamk_workspace, void* stream);
 int64_t shg_conv3d_k533_workspace_bytes_ex(int B, int T, int H, int W, int row_order);
 int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, int W, int row_order, void* stream);
 int shg_conv3d_k533_dgrad_rows(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "shg_conv3d_k533_workspace_bytes": ([I, I, I, I], c_int64),
     "shg_conv3d_k533_prepare": ([P, I, I, I, I, P], c_int),
     "shg_conv3d_k533_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P], c_int),
+    "shg_conv3d_k533_fwd_rows": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P], c_int),
     "shg_streamk_workspace_bytes": ([], c_int64),
     "shg_streamk_workspace_init": ([P, P], c_int),
     "shg_conv3d_k533_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, P, P], c_int),

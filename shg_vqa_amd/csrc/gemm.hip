@@ -210,9 +210,18 @@ template <typename T, int NTHR> struct ConvColSrc {
     // 512-byte pieces of every position.
     static constexpr bool NPERM = true;
     int nblk = 0, lblk0 = 0;
+    // lpt: the taps of a channel block in the order centre (all 49 positions), edges (42), corners (36) - with the zero-border
+    // skipping (tpp) the tiles of a launch differ in length by up to 27 %, and the workgroups are handed out in this order: longest
+    // first keeps the last round short (position-major rows without it: 2.25 -> 2.08 ms for conv1, with it see DESIGN.md 9 (10))
+    int lpt = 0;
     __device__ __forceinline__ int64_t col_of_lblock(int64_t lb) const {            // lb: logical block of the whole problem
         if (!nblk) return lb * 256;
-        const uint32_t L = (uint32_t)lb, c = (L * 11651u) >> 19, t = L - c * 45u;
+        const uint32_t L = (uint32_t)lb, c = (L * 11651u) >> 19;
+        uint32_t t = L - c * 45u;
+        if (lpt) {
+            const uint32_t j = t < 25u ? t - 5u : t - 25u, k3 = j >> 2, e = j & 3u;
+            t = t < 5u ? 9u * t + 4u : (t < 25u ? 9u * k3 + 1u + 2u * e : 9u * k3 + (e & 1u) * 2u + (e >> 1) * 6u);
+        }
         return (int64_t)(t * (uint32_t)nblk + c) * 256;
     }
     __device__ __forceinline__ int64_t col_of_block(int64_t bn) const { return col_of_lblock(lblk0 + bn); }
@@ -355,6 +364,7 @@ template <typename TC> struct Epilogue {
     int no_side;              // 1: the row writers' up-front-load forms are switched off ("epilogue_side" tuning switch, A/B runs)
     int save_grad;            // forward: `pre` receives act'(u) instead of u (SHG_ACT_SAVE_GRAD)
     double* sumsq;            // conv weight gradient on the 8-phase kernel, plain stores of whole tiles: *sumsq += sum of C[m, n]^2
+    const int32_t* prow;      // optional row remap of `pre`: row m of the second output goes to row prow[m]
 };
 
 __device__ __forceinline__ float act_grad_rt(float u, int act, bool fast) {
@@ -534,7 +544,7 @@ template <> struct RowWriter<bf16_t> {
                           b[0] + bias8[4], b[1] + bias8[5], b[2] + bias8[6], b[3] + bias8[7]};
             const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
             bf16_t* dst = ep.c + crow * ep.ldc + n;
-            bf16_t* pre = ep.pre ? ep.pre + m * N + n : nullptr;
+            bf16_t* pre = ep.pre ? ep.pre + (ep.prow ? (int64_t)ep.prow[m] : m) * N + n : nullptr;
             if (ep.gpre) {                               // (nv == 8: N % 8 == 0 is checked on the host)
                 const bf16x8 gp = *reinterpret_cast<const bf16x8*>(ep.gpre + m * N + n);
                 bf16x8 o;
@@ -655,7 +665,7 @@ template <> struct RowWriter<float> {
             float u[4] = {a[0] + bias4[0], a[1] + bias4[1], a[2] + bias4[2], a[3] + bias4[3]};
             const int64_t crow = ep.crow ? (int64_t)ep.crow[m] : m;
             float* dst = ep.c + crow * ep.ldc + n;
-            float* pre = ep.pre ? ep.pre + m * N + n : nullptr;
+            float* pre = ep.pre ? ep.pre + (ep.prow ? (int64_t)ep.prow[m] : m) * N + n : nullptr;
             if (ep.gpre) {                               // (N % 8 == 0 is checked on the host)
                 const f32x4 gp = *reinterpret_cast<const f32x4*>(ep.gpre + m * N + n);
                 if (drop) {
@@ -2091,7 +2101,13 @@ extern "C" int shg_streamk_workspace_init(void* ws, void* stream) {
 extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
                                    int H, int W, int Cin, int Cout, int act, int pad_out, void* y_pre,
                                    const void* workspace, void* streamk_ws, void* stream) {
-    SHG_REPEAT(64, shg_conv3d_k533_fwd(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, workspace, streamk_ws, stream));
+    return shg_conv3d_k533_fwd_rows(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, nullptr, workspace, streamk_ws, stream);
+}
+
+extern "C" int shg_conv3d_k533_fwd_rows(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
+                                        int H, int W, int Cin, int Cout, int act, int pad_out, void* y_pre, const int32_t* pre_rows,
+                                        const void* workspace, void* streamk_ws, void* stream) {
+    SHG_REPEAT(64, shg_conv3d_k533_fwd_rows(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, pre_rows, workspace, streamk_ws, stream));
     if (!x || !w || !y) return fail_arg("conv3d_fwd: null pointer");
     if (streamk_ws && !al16(streamk_ws)) return fail_arg("conv3d_fwd: streamk workspace must be 16-byte aligned");
     if (y_pre && !al16(y_pre)) return fail_arg("conv3d_fwd: y_pre must be 16-byte aligned");
@@ -2106,10 +2122,12 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
         ConvRowSrc<float, 256> sa{(const float*)x, pos_in, 0, M, g};
         PlainSrc<float, true> sb{(const float*)w, K, 0, N, K};
         Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (float*)y_pre, 0};
+        ep.prow = pre_rows;
         return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);
     }
     PlainSrc<bf16_t, true> sb{(const bf16_t*)w, K, 0, N, K};
     Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre, 0};
+    ep.prow = pre_rows;
     if (use_gemm8(M, N, K, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2, N * K * 2)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
         return launch8<bf16_t, decltype(sa), decltype(sb), 1>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", 1, streamk_ws);
@@ -2125,9 +2143,10 @@ extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bi
 // sum of squares of `blks` 256-column blocks (logical blocks lb0 .. of a [rows, R] fp32 matrix, the weight gradient's column
 // order) / of a contiguous fp32 range, added to *out
 __global__ __launch_bounds__(256) void sumsq_blocks_kernel(const float* __restrict__ w, int64_t R, int rows, int lb0, int blks, int nblk,
-                                                           double* __restrict__ out) {
+                                                           int lpt, double* __restrict__ out) {
     ConvColSrc<bf16_t, 512> m{};
     m.nblk = nblk;
+    m.lpt = lpt;
     double acc = 0.0;
     const int64_t segs = (int64_t)rows * blks;
     for (int64_t q = blockIdx.x; q < segs; q += gridDim.x) {
@@ -2181,6 +2200,7 @@ static int conv_wgrad_core(const void* x, const void* dy, float* dw, int dtype, 
             sb.tpp_magic = (1 << 20) / sb.tpp + 1;
             sb.Hin = H;
             sb.Win = W;
+            sb.lpt = (sb.nblk && (tuning(TUNE_CONV_K_ORDER) & 16)) ? 1 : 0;
         }
         // Tile-count quantisation: conv1's 3 x 360 = 1 080 tiles are 4.22 rounds of 256 CUs - the fifth round runs 56
         // workgroups for the full K = 18 816 while 200 CUs idle (0.36 ms of a 2.3 ms launch, the last kernel of backward).
@@ -2215,7 +2235,7 @@ static int conv_wgrad_core(const void* x, const void* dy, float* dw, int dtype, 
                 if (int e = launch8<float, decltype(sa), decltype(sb)>(sa, sb, ep, cn, gn_b * 256, Mo, st, "conv3d_k533_wgrad", split)) return e;
                 if (fused) {
                     hipLaunchKernelGGL(sumsq_blocks_kernel, dim3((unsigned)std::min<int64_t>(1024, cn * gn_b)), dim3(256), 0, st, c_rows, Ncols, cn,
-                                       (int)gn_a, (int)gn_b, sb.nblk, sumsq);
+                                       (int)gn_a, (int)gn_b, sb.nblk, sb.lpt, sumsq);
                     return check_launch("conv3d_k533_wgrad_sumsq");
                 }
                 return 0;

@@ -480,7 +480,7 @@ def streamk_workspace(device):
     return ws
 
 
-def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None, order=0):
+def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None, order=0, pre_rows=None):
     """x_cl [B,T,H+2,W+2,Cin] (zero border); w_cl [Cout,5,3,3,Cin]; -> y [B,T-4,H,W,Cout]
     (or written into the interior of a zero-bordered [B,T-4,H+2,W+2,Cout] buffer when pad_out)."""
     _dev(x_cl, w_cl, bias, out)
@@ -500,8 +500,11 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, wan
         pre = pre_out if pre_out is not None else torch.empty((B, T - 4, H, W, cout), dtype=x_cl.dtype, device=x_cl.device)
         _need(pre.is_contiguous() and pre.dtype == x_cl.dtype and pre.numel() == B * (T - 4) * H * W * cout, "bad pre_out")
     sk = streamk_workspace(x_cl.device) if x_cl.dtype == torch.bfloat16 else None
-    _lib.call("shg_conv3d_k533_fwd", x_cl.data_ptr(), w_cl.data_ptr(), _p(bias), out.data_ptr(), _dt(x_cl), B, T, H, W, cin,
-              cout, act, 1 if pad_out else 0, _p(pre), ws.data_ptr(), _p(sk), _stream())
+    if pre_rows is not None:                      # row m of pre goes to row pre_rows[m] (e.g. conv_row_table: a standard-order forward, pre position-major)
+        _dev(pre_rows)
+        _need(pre_rows.dtype == torch.int32 and pre_rows.is_contiguous() and pre_rows.numel() == B * (T - 4) * H * W, "pre_rows must be int32 [rows]")
+    _lib.call("shg_conv3d_k533_fwd_rows", x_cl.data_ptr(), w_cl.data_ptr(), _p(bias), out.data_ptr(), _dt(x_cl), B, T, H, W, cin,
+              cout, act, 1 if pad_out else 0, _p(pre), _p(pre_rows), ws.data_ptr(), _p(sk), _stream())
     return (out, pre) if want_pre else out
 
 

@@ -1061,6 +1061,10 @@ def test_conv_forward_at_bench_shape_streamk_integer_exact_and_bf16_rows(K, name
     print("%s fwd B=32: max |pre - ref| = %.3e, max |gelu - ref| = %.3e (|ref| max %.3f)" % (name, err_pre, err_act, scale))
     assert err_pre <= 2 ** -8 * scale + 1e-3 and err_act <= 2 ** -8 * scale + 1e-3      # one bf16 rounding of an fp32 sum
     assert int(_lib.lib().shg_gemm_streamk_launches()) == before + 2, "the stream-K path was not taken"
+    # the step's form: standard-order forward whose pre-activation rows go through the position-major table (stream-K epilogue)
+    tbl = K.conv_row_table(B, T, H, W, DEV)
+    yg2, pre2 = K.conv3d_k533_fwd(xr, wr, br, act=1, want_pre=True, pre_rows=tbl)
+    assert torch.equal(yg2, yg) and torch.equal(pre2.view(-1, Cout)[tbl.long()], pre.view(-1, Cout))
 
 
 @pytest.mark.parametrize("name,Cin,T", [("conv1", 2048, 16), ("conv2", 768, 12)])
@@ -1105,7 +1109,7 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     dy_pm = torch.empty(B * To * H * W, Cout, device=DEV)
     dy_pm[tbl] = dyi.view(-1, Cout)
     dy_pm = dy_pm.view(B, To, H, W, Cout).bfloat16()
-    for skip in (14, 6):                                  # with and without the skipping (bit 3 of conv_k_order)
+    for skip in (30, 14, 6):                                # with and without the skipping (bit 3 of conv_k_order)
         _lib.set_tuning("conv_k_order", skip)
         try:
             dw.fill_(5.0)
@@ -1119,7 +1123,7 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
             assert torch.equal(dw.view(Cout, -1), ref), skip
             assert abs(ss.item() - want) <= 1e-6 * want, (skip, ss.item(), want)
         finally:
-            _lib.set_tuning("conv_k_order", 14)
+            _lib.set_tuning("conv_k_order", 30)
     del ref, xi, dyi, dy_pm
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
     xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
@@ -1150,6 +1154,9 @@ def test_conv_row_order_position_major_forward_and_input_gradient(K):
     y1, pre1 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=True, want_pre=True, order=1)
     assert torch.equal(y0, y1)
     assert torch.equal(pre1.view(-1, Cout)[tbl], pre0.view(-1, Cout))
+    # ... and a forward in standard order that writes only its pre-activation through the table (what the step does)
+    y2, pre2 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=True, want_pre=True, pre_rows=K.conv_row_table(B, T, H, W, DEV))
+    assert torch.equal(y0, y2) and torch.equal(pre2, pre1)
     d0 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=False)
     d1 = K.conv3d_k533_fwd(x, w, b, 1, pad_out=False, order=1)
     assert torch.equal(d1.view(-1, Cout)[tbl], d0.view(-1, Cout))

@@ -38,13 +38,13 @@ def timed(fn):
 
 
 for rnd in range(2):
-    for order, sw in ((0, 14), (1, 6), (1, 14)):
+    for order, sw in ((0, 30), (1, 6), (1, 14), (1, 30)):
         _lib.set_tuning("conv_k_order", sw)
         t1 = timed(lambda: K.conv3d_k533_wgrad_sumsq(x_cl, dy1, dw1, ss, order=order))
         t2 = timed(lambda: K.conv3d_k533_wgrad_sumsq(y1, dy2, dw2, ss, order=order))
         t3 = timed(lambda: K.conv3d_k533_wgrad(x_cl, dy1, dw1, accumulate=True, c0=0, cn=512, order=order))
         tf = timed(lambda: K.conv3d_k533_fwd(x_cl, w1, b1, 1, pad_out=True, out=y1, order=order))
         y1[:, :, 1:8, 1:8] = torch.randn(B, 12, 7, 7, 768, device=dev).bfloat16()
-        print("rows %s, skip %s: conv1 weight gradient %7.1f us   conv2 weight gradient %6.1f us   conv1 slice of 512 channels %7.1f us   conv1 forward %7.1f us"
-              % ("position-major" if order else "standard      ", "on " if sw & 8 and order else "off", t1, t2, t3, tf), flush=True)
-_lib.set_tuning("conv_k_order", 14)
+        print("rows %s, skip %-24s: conv1 weight gradient %7.1f us   conv2 weight gradient %6.1f us   conv1 slice of 512 channels %7.1f us   conv1 forward %7.1f us"
+              % ("position-major" if order else "standard      ", ("on, longest taps first" if sw & 16 else "on ") if sw & 8 and order else "off", t1, t2, t3, tf), flush=True)
+_lib.set_tuning("conv_k_order", 30)
