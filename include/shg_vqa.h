@@ -157,6 +157,14 @@ int shg_bias_act_bwd_view(const void* x, const float* bias, const void* dy, void
                           int dtype, int64_t rows, int cols, int act, float p_drop, const uint64_t* seed_state,
                           uint64_t stream_id, int64_t dy_rows_per_group, int64_t dy_group_stride, int64_t dy_row_offset,
                           void* dx2, const int32_t* dx2_rows, void* stream);
+/* ... and with x_rows (int32 [rows] or NULL): result row r reads x at row x_rows[r] and writes dx at row x_rows[r] (dy, dx2 and the
+ * bias-gradient sums are indexed by r as before) - the conv stack's backward with its saved pre-activation and its dense result in
+ * position-major rows (shg_conv3d_k533_prepare_ex, row_order 1) while the incoming token gradients stay in sequence order.  No
+ * dropout in this form. */
+int shg_bias_act_bwd_rows(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial, int n_partials,
+                          int dtype, int64_t rows, int cols, int act, float p_drop, const uint64_t* seed_state,
+                          uint64_t stream_id, int64_t dy_rows_per_group, int64_t dy_group_stride, int64_t dy_row_offset,
+                          void* dx2, const int32_t* dx2_rows, const int32_t* x_rows, void* stream);
 
 /* z = dropout(act(x + bias)) + residual;  y = LayerNorm(z) * gamma + beta.
  * Replaces BertAttOutput / BertOutput (modeling_capsbert.py:431-435, :485-489), the decoder's

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "shg_bias_act_fwd": ([P, P, P, I, L, I, I, F, P, U, P], c_int),
     "shg_bias_act_bwd": ([P, P, P, P, P, I, I, L, I, I, F, P, U, P], c_int),
     "shg_bias_act_bwd_view": ([P, P, P, P, P, I, I, L, I, I, F, P, U, L, L, L, P, P, P], c_int),
+    "shg_bias_act_bwd_rows": ([P, P, P, P, P, I, I, L, I, I, F, P, U, L, L, L, P, P, P, P], c_int),
     "shg_bias_act_drop_res_ln_fwd": ([P, P, P, P, P, P, P, P, P, I, L, I, I, F, F, P, U, P], c_int),
     "shg_bias_act_drop_res_ln_bwd": ([P, P, P, P, P, P, P, P, P, P, P, P, I, I, L, I, I, F, P, U, P], c_int),
     "shg_colsum_partial": ([P, I, L, I, L, P, I, P], c_int),

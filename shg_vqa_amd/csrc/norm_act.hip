@@ -274,6 +274,7 @@ struct BwdView {
     int64_t dy_rows_per_group, dy_group_stride, dy_row_offset;      // rows_per_group == 0: dy is [rows, cols] as it is
     void* dx2;                                                      // second output (same dtype) or null
     const int32_t* row2;                                            // its row of result row r (null: r)
+    const int32_t* xrow;                                            // row of x AND of dx that belongs to row r (null: r)
 };
 template <typename T, int ACT, int NCH, bool DROP>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
@@ -302,12 +303,13 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__
                                    ? (row / vw.dy_rows_per_group) * vw.dy_group_stride + vw.dy_row_offset + row % vw.dy_rows_per_group
                                    : row;
         const int64_t row2 = vw.row2 ? (int64_t)vw.row2[row] : row;
+        const int64_t xr = vw.xrow ? (int64_t)vw.xrow[row] : row;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int ch = lane + i * 64;
             if (ch < nchunk) {
                 const int c0 = ch * V;
-                const int64_t off = row * cols + c0;
+                const int64_t off = xr * cols + c0;
                 Vec16<T> xv = load16(x + off), gv = load16(dy + dy_row * cols + c0), dv;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
@@ -753,11 +755,21 @@ extern "C" int shg_bias_act_bwd_view(const void* x, const float* bias, const voi
                                      int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
                                      const uint64_t* seed_state, uint64_t stream_id, int64_t dy_rows_per_group,
                                      int64_t dy_group_stride, int64_t dy_row_offset, void* dx2, const int32_t* dx2_rows, void* stream) {
+    return shg_bias_act_bwd_rows(x, bias, dy, dx, dbias_partial, n_partials, dtype, rows, cols, act, p_drop, seed_state, stream_id,
+                                 dy_rows_per_group, dy_group_stride, dy_row_offset, dx2, dx2_rows, nullptr, stream);
+}
+
+extern "C" int shg_bias_act_bwd_rows(const void* x, const float* bias, const void* dy, void* dx, float* dbias_partial,
+                                     int n_partials, int dtype, int64_t rows, int cols, int act, float p_drop,
+                                     const uint64_t* seed_state, uint64_t stream_id, int64_t dy_rows_per_group,
+                                     int64_t dy_group_stride, int64_t dy_row_offset, void* dx2, const int32_t* dx2_rows,
+                                     const int32_t* x_rows, void* stream) {
     if (!x || !dy || !dx) return fail_arg("bias_act_bwd: null pointer");
+    if (x_rows && p_drop > 0.f) return fail_arg("bias_act_bwd_rows: a row table with dropout is not supported (the mask is indexed by x's element)");
     if (dy_rows_per_group < 0 || (dy_rows_per_group > 0 && (dy_row_offset < 0 || dy_group_stride < dy_rows_per_group + dy_row_offset)))
         return fail_arg("bias_act_bwd: bad view of dy");
     if (dx2 && (reinterpret_cast<uintptr_t>(dx2) & 15)) return fail_arg("bias_act_bwd: dx2 must be 16-byte aligned");
-    const BwdView vw{dy_rows_per_group, dy_group_stride, dy_row_offset, dx2, dx2_rows};
+    const BwdView vw{dy_rows_per_group, dy_group_stride, dy_row_offset, dx2, dx2_rows, x_rows};
     if (int e = check_cols(dtype, cols, "bias_act_bwd: unsupported cols", 16)) return e;
     if (n_partials < 1 || n_partials > MAX_PARTIALS) return fail_arg("bias_act_bwd: bad n_partials");
     if (rows <= 0) return rows == 0 ? 0 : fail_arg("bias_act_bwd: negative rows");

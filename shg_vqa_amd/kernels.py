@@ -202,7 +202,7 @@ def bias_act_fwd(x, bias, act, p_drop=0.0, seed_state=None, stream_id=0):
     return y
 
 
-def bias_act_bwd(x, bias, dy, act, p_drop=0.0, seed_state=None, stream_id=0, want_dbias=True, dy_groups=None, out2=None):
+def bias_act_bwd(x, bias, dy, act, p_drop=0.0, seed_state=None, stream_id=0, want_dbias=True, dy_groups=None, out2=None, x_rows=None):
     """-> (dx, dbias_partial [n_partials, cols] or None).
     dy_groups = (rows_per_group, group_stride, row_offset): dy is a contiguous [groups * group_stride, cols] tensor of which every
     group contributes rows row_offset .. row_offset + rows_per_group (shg_bias_act_bwd_view); out2 = (buffer, int32 row table):
@@ -225,8 +225,11 @@ def bias_act_bwd(x, bias, dy, act, p_drop=0.0, seed_state=None, stream_id=0, wan
         _dev(buf2, tbl2)
         _need(buf2.dtype == x.dtype and buf2.is_contiguous() and buf2.shape[-1] == cols, "out2 buffer must be contiguous [.., cols] of x's dtype")
         _need(tbl2.dtype == torch.int32 and tbl2.numel() == rows and tbl2.is_contiguous(), "out2 row table must be int32 [rows]")
-    _lib.call("shg_bias_act_bwd_view", x.data_ptr(), _p(bias), dy.data_ptr(), dx.data_ptr(), _p(part), npart, _dt(x), rows,
-              cols, act, float(p_drop), _p(seed_state), int(stream_id), rpg, gs, off, _p(buf2), _p(tbl2), _stream())
+    if x_rows is not None:                         # result row r <-> row x_rows[r] of x and dx (shg_bias_act_bwd_rows)
+        _dev(x_rows)
+        _need(x_rows.dtype == torch.int32 and x_rows.numel() == rows and x_rows.is_contiguous() and p_drop == 0.0, "x_rows: int32 [rows], no dropout")
+    _lib.call("shg_bias_act_bwd_rows", x.data_ptr(), _p(bias), dy.data_ptr(), dx.data_ptr(), _p(part), npart, _dt(x), rows,
+              cols, act, float(p_drop), _p(seed_state), int(stream_id), rpg, gs, off, _p(buf2), _p(tbl2), _p(x_rows), _stream())
     return dx, part
 
 

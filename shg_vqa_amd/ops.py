@@ -503,7 +503,10 @@ class _VisualConvTokens(torch.autograd.Function):
     def forward(ctx, x_cl, y1p, pre1, w1, b1, w2, b2, cls_token, pe):
         E = engine()
         cdt = E.compute_dtype
-        y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True)
+        # (as for conv1: forward in standard row order, the saved pre-activation in the position-major rows its backward works on)
+        ctx.order2 = E.conv1_row_order
+        rows2 = K.conv_row_table(y1p.shape[0], y1p.shape[1], y1p.shape[2] - 2, y1p.shape[3] - 2, y1p.device) if ctx.order2 else None
+        y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True, pre_rows=rows2)
         B = x_cl.shape[0]
         C = y2.shape[-1]
         out = K.tokens_assemble(y2.view(B, -1, C), cls_token._shg_store.view(-1), pe._shg_store)     # cls + positions, one kernel
@@ -539,10 +542,18 @@ class _VisualConvTokens(torch.autograd.Function):
         # input-gradient convolution gathers from (no F.pad pass) - a persistent buffer whose border stays zero.
         To, H, W = pre2.shape[1], pre2.shape[2], pre2.shape[3]
         fused = d_out.is_contiguous() and not torch.cuda.is_current_stream_capturing() and os.environ.get("SHG_CONV_BWD_FUSED", "1") != "0"
+        order2 = ctx.order2
+        tbl2 = K.conv_row_table(B, To + 4, H, W, d_out.device) if order2 else None
         if fused:
+            # (order2: pre2 and the dense result d2 - the weight gradient's operand - in position-major rows; the token gradients
+            #  and the padded copy are indexed by the sequence order as before)
             d2p, rows2 = _padded_grad_buffer(E, B, To, H, W, C, pre2.dtype, d_out.device)
-            d2, part = K.bias_act_bwd(pre2, None, d_out, ACT_GELU, want_dbias=True, dy_groups=(n_tok - 1, n_tok, 1), out2=(d2p, rows2))
+            d2, part = K.bias_act_bwd(pre2, None, d_out, ACT_GELU, want_dbias=True, dy_groups=(n_tok - 1, n_tok, 1), out2=(d2p, rows2),
+                                      x_rows=tbl2)
         else:
+            if order2:                                     # (rare path: back to sequence order)
+                pre2 = pre2.view(-1, C)[tbl2.long()].view(pre2.shape)
+                order2 = 0
             d_tok = d_out[:, 1:].contiguous().view(pre2.shape)
             d2, part = K.bias_act_bwd(pre2, None, d_tok, ACT_GELU, want_dbias=True)
         _acc_vec(part, b2)
@@ -566,7 +577,7 @@ class _VisualConvTokens(torch.autograd.Function):
             # conv2's weight gradient goes first (its exchange runs under conv1's), and conv1's leaves as two launches over
             # output channels - 2/3 (720 tiles of 256 x 256 = 3 rounds on 256 CUs) and 1/3 (360 tiles = 2 rounds: the same
             # five rounds as one launch of 1 080) - so that the exchange of the first part runs under the second.
-            K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True)
+            K.conv3d_k533_wgrad(y1p, d2, w2._shg_grad, accumulate=True, order=order2)
             E.grad_written(w2)
             cout, per = w1._shg_grad.shape[0], w1._shg_grad[0].numel()
             cut = (cout // 256) * 2 // 3 * 256
@@ -581,11 +592,11 @@ class _VisualConvTokens(torch.autograd.Function):
             _conv_wgrad(E, x_cl, d1, w1, order1)
             _event_done(tm)
             E.grad_written(w1)
-            _conv_wgrad(E, y1p, d2, w2)
+            _conv_wgrad(E, y1p, d2, w2, order2)
             E.grad_written(w2)
         else:
             with _WgradStream(y1p, d2):
-                _conv_wgrad(E, y1p, d2, w2)
+                _conv_wgrad(E, y1p, d2, w2, order2)
             E.grad_written(w2)
             with _WgradStream(x_cl, d1):
                 _conv_wgrad(E, x_cl, d1, w1, order1)

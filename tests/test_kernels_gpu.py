@@ -1136,6 +1136,25 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     assert err <= 2e-4 * ref.abs().max().item() + 1e-3          # fp32 accumulation order only
 
 
+def test_bias_act_bwd_with_a_row_table(K):
+    """shg_bias_act_bwd_rows: result row r reads x / writes dx at row x_rows[r]; dy (a grouped view), the scattered second output and
+    the bias-gradient partial sums stay indexed by r."""
+    B, S, C = 3, 40, 768
+    gen = torch.Generator().manual_seed(9)
+    rows = B * S
+    perm = torch.randperm(rows, generator=gen).to(DEV)
+    x = torch.randn(rows, C, generator=gen).to(DEV).bfloat16()
+    dy = torch.randn(B, S + 1, C, generator=gen).to(DEV).bfloat16()          # one extra leading row per group, skipped
+    tbl2 = torch.randperm(rows + 7, generator=gen)[:rows].to(DEV).int()
+    buf0 = torch.zeros(rows + 7, C, device=DEV, dtype=torch.bfloat16)
+    buf1 = torch.zeros_like(buf0)
+    dx0, p0 = K.bias_act_bwd(x, None, dy, 1, want_dbias=True, dy_groups=(S, S + 1, 1), out2=(buf0, tbl2))
+    x_pm = torch.empty_like(x)
+    x_pm[perm] = x                                                           # row r of x lives at row perm[r]
+    dx1, p1 = K.bias_act_bwd(x_pm, None, dy, 1, want_dbias=True, dy_groups=(S, S + 1, 1), out2=(buf1, tbl2), x_rows=perm.int())
+    assert torch.equal(dx1[perm], dx0) and torch.equal(buf0, buf1) and torch.equal(p0, p1)
+
+
 def test_conv_row_order_position_major_forward_and_input_gradient(K):
     """Row order 1 of the convolution GEMMs (include/shg_vqa.h): the forward's dense pre-activation comes out in position-major
     rows (same values, the padded output is a layout and does not change), shg_conv3d_k533_dgrad_rows scatters its rows by a table."""
