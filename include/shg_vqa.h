@@ -71,6 +71,10 @@ int64_t shg_gemm_streamk_launches(void);
  * partial-sum slot a tail publishes to, number of published parts the owner adds}.  Returns 1, or 0 when the workgroup has no
  * such segment (SHG_ERR_INVALID on bad arguments).  Pure host arithmetic, no GPU needed. */
 int shg_streamk_plan(int n_tiles, int nk, int block, int seg, int* out);
+/* the WEIGHTED plan (tiles of different length: the conv forward in position-major row order leaves out the taps that read the
+ * zero border for every row of a tile): nk_tile[n_tiles] K-tiles per tile; same descriptor, slots 3 tile + part; the XCDs' runs
+ * of tiles are cut by K-tiles, not by tiles; -1 = these lengths do not fit the plan */
+int shg_streamk_plan_weighted(int n_tiles, const uint16_t* nk_tile, int block, int seg, int* out);
 /* Caller-owned workspace of that split (partial-sum slots + flags): shg_streamk_workspace_bytes() bytes of device memory,
  * 16-byte aligned, initialised ONCE by shg_streamk_workspace_init (zeroes the flags on `stream`; launches leave them zero).
  * One workspace serves the launches of one stream at a time; pass it to shg_conv3d_k533_fwd (NULL: no split). */
@@ -329,18 +333,20 @@ int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dt
  * spatial position then owns whole K-tiles of the weight gradient's contraction, and a tile (one kernel tap) skips the positions
  * where its tap reads the zero border (Conv3d padding (0, 1, 1), modeling_capsbert.py:560-566: 18 % of the products of a 3 x 3
  * window on a 7 x 7 grid are with zeros) - same sums, bit for bit, in fewer K-tiles.
- *   shg_conv3d_k533_workspace_bytes_ex / _prepare_ex: tables for a row order; order 1 appends a third table after the two of
- *     order 0 (each ((M * 4 + 255) / 256) * 256 bytes): std2row[m] = position-major row of standard row m.
+ *   shg_conv3d_k533_workspace_bytes_ex / _prepare_ex: tables for a row order; order 1 appends two tables after the two of
+ *     order 0 (each ((M * 4 + 255) / 256) * 256 bytes): std2row[m] = position-major row of standard row m, row2std = its inverse.
  *   shg_conv3d_k533_fwd takes either workspace (its dense outputs y_pre / y then have that row order; pad_out output is a layout,
  *     not an order).  shg_conv3d_k533_dgrad_rows: row m of dx is written at dx_rows[m] (the NEXT layer's std2row: its input
  *     gradient arrives in the order its weight gradient contracts over); NULL = shg_conv3d_k533_dgrad.
  *   shg_conv3d_k533_wgrad_ex: the general weight gradient - slice [c0, c0 + cn), accumulate or overwrite, optional fused sum of
  *     squares (only with accumulate = 0), row order of x's table / dy's rows. */
-/* shg_conv3d_k533_fwd whose pre-activation row m is written at row pre_rows[m] (NULL: row m): a forward in standard row order
- * (the faster one: neighbouring rows share input lines) that leaves y_pre in the order the backward works in. */
+/* shg_conv3d_k533_fwd with row tables: the pre-activation row m is written at row pre_rows[m], the dense output (pad_out = 0) row m
+ * at row y_rows[m] (NULL: row m) - e.g. a forward in standard row order that leaves y_pre in the order the backward works in.
+ * row_order = the order of the workspace's tables; with 1 (position-major) a tile leaves out the taps that read only the zero
+ * border for all of its rows, and the stream-K launch balances the tiles' different lengths with its weighted plan. */
 int shg_conv3d_k533_fwd_rows(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T, int H,
                              int W, int Cin, int Cout, int act, int pad_out, void* y_pre, const int32_t* pre_rows,
-                             const void* workspace, void* streamk_workspace, void* stream);
+                             const int32_t* y_rows, int row_order, const void* workspace, void* streamk_workspace, void* stream);
 int64_t shg_conv3d_k533_workspace_bytes_ex(int B, int T, int H, int W, int row_order);
 int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, int W, int row_order, void* stream);
 int shg_conv3d_k533_dgrad_rows(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,

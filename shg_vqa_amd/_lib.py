@@ -24,6 +24,7 @@ _SIGNATURES = {
     "shg_tuning_name": ([I], c_char_p),
     "shg_gemm_streamk_launches": ([], L),
     "shg_streamk_plan": ([I, I, I, I, P], c_int),
+    "shg_streamk_plan_weighted": ([I, P, I, I, P], c_int),
     "shg_hungarian_per_frame": ([P, I, I, I, I, P, P, L, P, P, P, P], c_int),
     "shg_lsap_batched": ([P, I, I, I, P, P, P, P], c_int),
     "shg_weighted_ce_fwd": ([P, I, L, I, P, P, L, P, P, P], c_int),
@@ -52,7 +53,7 @@ _SIGNATURES = {
     "shg_conv3d_k533_workspace_bytes": ([I, I, I, I], c_int64),
     "shg_conv3d_k533_prepare": ([P, I, I, I, I, P], c_int),
     "shg_conv3d_k533_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P], c_int),
-    "shg_conv3d_k533_fwd_rows": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P], c_int),
+    "shg_conv3d_k533_fwd_rows": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, I, P, P, P], c_int),
     "shg_streamk_workspace_bytes": ([], c_int64),
     "shg_streamk_workspace_init": ([P, P], c_int),
     "shg_conv3d_k533_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, P, P], c_int),

@@ -61,7 +61,9 @@ enum Tune {
                                // storage order (tap-major).  Bit 2, weight gradient: 256-column blocks channel-block-major, so that the
                                // tiles an XCD runs together gather the same input lines.  Bit 3, weight gradient with position-major
                                // rows (shg_conv3d_k533_wgrad_ex, row_order 1): skip the K-tiles of positions where the tile's tap reads
-                               // the zero border.  Bit 4: with that, the taps of a channel block longest first (30) - "conv_k_order"
+                               // the zero border.  Bit 4: with that, the taps of a channel block longest first.  Bit 5, forward with position-major
+                               // rows (shg_conv3d_k533_fwd_rows, row_order 1): a tile leaves out the taps that read only the zero border
+                               // for all its rows; the stream-K launch then uses the weighted plan (62) - "conv_k_order"
     TUNE_WGRAD_GROUP_CAP,      // grouped weight gradients: workgroups per launch (256 = one round of the CUs) - "wgrad_group_cap"
     TUNE_WGRAD_GROUP_SPLIT,    // ... and parts of every problem's contraction (1) - "wgrad_group_split"
     TUNE_REPEAT_FAMILY,        // DIAGNOSTIC (0): bit mask of kernel families whose every launch is issued TWICE (all idempotent:

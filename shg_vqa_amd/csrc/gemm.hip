@@ -122,13 +122,14 @@ struct ConvGeom {
     int Cin, Hp, Wp;          // padded input plane
     uint32_t inv_cin;         // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, inv_cin) for k < 2^32 / Cin
     int kperm;                // 8-phase kernel: visit the K-tiles channel-block-major (all 45 taps of 64 channels, then the next 64)
+    int rpp;                  // forward in position-major row order: rows per spatial position (B To), 0 = every tap for every tile
 };
 static int conv_k_order(int Cin) {                     // 0: storage order; n: blocks of 64 * 2^(n-1) channels, n <= 3
     const int n = (int)tuning(TUNE_CONV_K_ORDER) & 3;
     return (n >= 1 && n <= 3 && Cin % (64 << (n - 1)) == 0) ? n : 0;
 }
 static ConvGeom conv_geom(int Cin, int Hp, int Wp) {
-    return ConvGeom{Cin, Hp, Wp, (uint32_t)(0x100000000ull / (uint32_t)Cin) + 1u, conv_k_order(Cin)};
+    return ConvGeom{Cin, Hp, Wp, (uint32_t)(0x100000000ull / (uint32_t)Cin) + 1u, conv_k_order(Cin), 0};
 }
 // tap < 45 -> (kt, kh, kw) by multiply-shift (exact on that range): the wave-uniform address math of the
 // direct-to-LDS loads sits in the instruction stream of the load phase, where an integer division costs ~30 instructions
@@ -137,6 +138,25 @@ __device__ __forceinline__ int64_t tap_offset(const ConvGeom& g, int tap) {
     return ((int64_t)(kt * g.Hp + kh) * g.Wp + kw) * g.Cin;
 }
 __device__ __forceinline__ uint32_t div_cin(const ConvGeom& g, uint32_t k) { return __umulhi(k, g.inv_cin); }
+
+// (kh, kw) taps that stay inside an H x W grid for position p = h W + w (bit kh * 3 + kw), and their union over the positions
+// that rows [m0, m0 + 255] of a position-major problem (rpp rows per position, M rows) belong to
+__host__ __device__ __forceinline__ uint32_t conv_valid9(int p, int H, int W) {
+    const int h = p / W, w = p - h * W;
+    uint32_t m = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            if (h + kh - 1 >= 0 && h + kh - 1 < H && w + kw - 1 >= 0 && w + kw - 1 < W) m |= 1u << (kh * 3 + kw);
+    return m;
+}
+__host__ __device__ __forceinline__ uint32_t conv_tile_mask9(int64_t m0, int64_t M, int rpp, int H, int W) {
+    const int64_t m1 = (m0 + 255 < M ? m0 + 255 : M - 1);
+    uint32_t m = 0;
+    for (int p = (int)(m0 / rpp); p <= (int)(m1 / rpp); ++p) m |= conv_valid9(p, H, W);
+    return m;
+}
 
 // A operand of the conv forward: rows = output positions (gathered), K = (tap, channel), K contiguous.
 template <typename T, int NTHR> struct ConvRowSrc {
@@ -147,11 +167,30 @@ template <typename T, int NTHR> struct ConvRowSrc {
     // of a 128-byte line within 45 consecutive K-tiles.
     static constexpr bool KPERM = true;
     static constexpr bool NPERM = false;
+    // Position-major rows (g.rpp rows per spatial position): a tile whose rows all sit at border positions drops the taps that read
+    // only the zero border for every one of them.  set_tile: the tile's list of taps - n9 of the 9 (kh, kw), their numbers as
+    // nibbles - and the K-tiles it leaves: 5 n9 taps x Cin / 64.  g.rpp == 0 (any row order): all 45.
+    __device__ __forceinline__ int set_tile(int64_t m0) {
+        if (!g.rpp) return 45 * (g.Cin >> 6);
+        const uint32_t mask = conv_tile_mask9(m0, M, g.rpp, g.Hp - 2, g.Wp - 2);
+        uint64_t nb = 0;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < 9; ++r)
+            if ((mask >> r) & 1u) { nb |= (uint64_t)r << (4 * c); ++c; }
+        nib = nb; n9 = c; ntaps = 5 * c;
+        ntaps_magic = (1u << 20) / ntaps + 1;
+        n9_magic = (1u << 20) / c + 1;
+        return (int)(ntaps * (uint32_t)(g.Cin >> 6));
+    }
     __device__ __forceinline__ int64_t k_of_tile(int64_t kt) const {
         // blocks of nb = 2^(kperm-1) K-tiles (64 nb channels): tile kt = (block, tap, tile in block).  Branch-free (a branch inside the
         // 8-phase loop splits its phases into basic blocks the scheduler cannot interleave across: +8-24 % per launch, measured)
         const uint32_t sh = (uint32_t)max(g.kperm - 1, 0), k = (uint32_t)kt, q = k >> sh, sub = k - (q << sh);
-        const uint32_t blk = (q * 11651u) >> 19, tap = q - blk * 45u;                 // q / 45 for q < 20 000
+        // q / ntaps, then the tap's place in the tile's list -> its number (x / d == (x * ((1 << 20) / d + 1)) >> 20 for x < 4 095)
+        const uint32_t blk = (q * ntaps_magic) >> 20, j = q - blk * ntaps;
+        const uint32_t k3 = (j * n9_magic) >> 20, s9 = j - k3 * n9;
+        const uint32_t tap = 9u * k3 + ((uint32_t)(nib >> (4u * s9)) & 15u);
         const uint32_t kp = tap * (uint32_t)g.Cin + (((blk << sh) + sub) << 6);
         return (int64_t)(g.kperm ? kp : k << 6);
     }
@@ -161,6 +200,8 @@ template <typename T, int NTHR> struct ConvRowSrc {
     ConvGeom g;
     int64_t base[Stage<T>::NCH];
     bool okr[Stage<T>::NCH];
+    uint32_t n9 = 9, ntaps = 45, ntaps_magic = (1u << 20) / 45 + 1, n9_magic = (1u << 20) / 9 + 1;      // set_tile()
+    uint64_t nib = 0x876543210ull;
     __device__ __forceinline__ void prepare(int tid) {
 #pragma unroll
         for (int i = 0; i < Stage<T>::NCH; ++i) {
@@ -1104,9 +1145,10 @@ struct StreamK {
     int* flags;
     int n_tiles;
     int sigma;               // cost of a tail K-tile in percent of a head K-tile (tails read their operand panels alone)
+    const void* wt;          // weighted plan (tiles of different length): StreamKW in kernel-argument memory, or null
 };
 constexpr int STREAMK_WGS = 256;
-constexpr int STREAMK_SLOTS = 512;                          // 2 per tile, at most 8 x 31 tiles
+constexpr int STREAMK_SLOTS = 768;                          // 3 per tile (the uniform plan uses 2), at most 8 x 31 tiles
 constexpr size_t STREAMK_SLOT = (size_t)256 * 256;          // floats per partial tile
 
 struct StreamKSeg {
@@ -1128,6 +1170,7 @@ __host__ __device__ __forceinline__ StreamKSeg streamk_plan(int n_tiles, int nk_
         if (seg > 0) return d;
         const int lt = j - T;
         d.tile = tile0 + lt; d.kb = 0; d.nk = h; d.owner = 1;
+        d.slot = 2 * d.tile;                                   // (an owner's slot: the first of its parts')
         d.parts = tl > 0 ? ((lt + 1) * tl - 1) / pt - (lt * tl) / pt + 1 : 0;
         return d;
     }
@@ -1139,7 +1182,142 @@ __host__ __device__ __forceinline__ StreamKSeg streamk_plan(int n_tiles, int nk_
     d.slot = 2 * d.tile + (start > lt * tl ? 1 : 0);
     return d;
 }
+// WEIGHTED plan: the tiles of a launch differ in length (the conv forward in position-major row order drops the taps that read the
+// zero border for every row of a tile: 20, 30, 40 or 45 of 45).  Same roles as the uniform plan - heads own a tile and compute its
+// first K-tiles in lockstep, the tail workgroups of the XCD share what is left, in tile order, as equal contiguous ranges - with
+// per-tile numbers:
+//   XCD x owns the run of tiles [t0_x, t0_x + R_x): still contiguous (neighbouring row blocks share input lines), but cut so that
+//     the K-TILES, not the tiles, divide evenly - an XCD of interior positions gets fewer tiles and more tail workgroups
+//     (16 <= R_x <= 31);
+//   head of tile t: [0, min(nk_t, h_x)), h_x the smallest h with 100 h T >= sigma Rem(h), Rem(h) = sum max(0, nk_t - h);
+//   tail j: K-tiles [j pt, (j + 1) pt) of the concatenated remainders, pt = ceil(Rem / T); a remainder r_t <= 2 pt (checked when
+//     the tables are built) is cut between at most three tails: slots 3 tile + (j - P_t / pt).
+// (Measured and dropped: equal ranges of the concatenated K-tiles for all 32 workgroups of an XCD, tiles dealt to the XCDs by
+//  weight - a perfect split on paper, 2.51 against 2.08 ms for conv1: the workgroups no longer walk K together and the tiles of an
+//  XCD no longer neighbour each other, and every operand panel is read alone.)
+// Tables (kernel-argument memory, scalar loads): per tile nk_t and P_t = the remainders in front of it in its XCD; per XCD
+// t0 / R / h / pt / Rem and for every tail the tile its range starts in.
+struct StreamKW {
+    uint16_t nk[256], P[256];
+    uint16_t h[8], pt[8], rem[8];
+    uint8_t t0[8], R[8];
+    uint8_t first[8][16];
+};
+template <typename WP>
+__host__ __device__ __forceinline__ StreamKSeg streamk_plan_w(WP w, int n_tiles, int block, int grid, int seg) {
+    StreamKSeg d{0, 0, 0, 0, 0, 0};
+    (void)n_tiles;
+    const int xcd = block & 7, j = block >> 3;
+    const int tile0 = w->t0[xcd], R = w->R[xcd], T = (grid >> 3) - R;
+    const int h = w->h[xcd], pt = w->pt[xcd], rem = w->rem[xcd];
+    if (j >= T) {                                              // head of tile j - T
+        if (seg > 0) return d;
+        const int t = tile0 + j - T, nk = w->nk[t], P = w->P[t], ht = nk < h ? nk : h, r = nk - ht;
+        d.tile = t; d.kb = 0; d.nk = ht; d.owner = 1; d.slot = 3 * t;
+        d.parts = r > 0 ? (P + r - 1) / pt - P / pt + 1 : 0;
+        return d;
+    }
+    const int lo = j * pt, hi = lo + pt < rem ? lo + pt : rem;
+    if (pt == 0 || lo >= hi) return d;
+    int cnt = 0;
+    for (int u = w->first[xcd][j]; u < R; ++u) {               // tiles with a remainder that meets [lo, hi), in order
+        const int t = tile0 + u, nk = w->nk[t], P = w->P[t], ht = nk < h ? nk : h, r = nk - ht;
+        if (r == 0) continue;
+        if (P >= hi) break;
+        if (P + r <= lo) continue;
+        if (cnt++ < seg) continue;
+        const int start = P > lo ? P : lo, end = P + r < hi ? P + r : hi;
+        d.tile = t; d.kb = ht + (start - P); d.nk = end - start; d.owner = 0;
+        d.slot = 3 * t + (j - P / pt);
+        return d;
+    }
+    return d;
+}
+// host: the tables for n_tiles tiles of nk[t] K-tiles; false = this launch cannot use the weighted plan
+static bool streamk_w_build(StreamKW& w, int n_tiles, const uint16_t* nk, int sigma) {
+    if (n_tiles < 128 || n_tiles >= 256) return false;
+    const int Wg = STREAMK_WGS / 8;
+    int nkmax_all = 0;
+    for (int t = 0; t < 256; ++t) { w.nk[t] = t < n_tiles ? nk[t] : 0; w.P[t] = 0; }
+    for (int t = 0; t < n_tiles; ++t) { nkmax_all = std::max<int>(nkmax_all, nk[t]); if (nk[t] < 1) return false; }
+    // head length of a run of tiles [a, a + R): the smallest h with 100 h T >= sigma Rem(h)
+    auto head_len = [&](int a, int R) -> int {
+        const int T = Wg - R;
+        int lo = 1, hi = nkmax_all;
+        while (lo < hi) {
+            const int mid = (lo + hi) / 2;
+            int64_t rem = 0;
+            for (int u = 0; u < R; ++u) rem += std::max(0, (int)nk[a + u] - mid);
+            if ((int64_t)100 * mid * T >= (int64_t)sigma * rem) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    // contiguous runs of 16 .. 31 tiles per XCD that minimise the LONGEST head (dynamic programme over the cut points: the launch
+    // takes as long as its slowest XCD; equal K-tiles per XCD is not it - an XCD's head length also depends on how many tail
+    // workgroups its tile count leaves)
+    {
+        const int INF = 1 << 30;
+        std::vector<int> best((size_t)9 * (n_tiles + 1), INF), from((size_t)9 * (n_tiles + 1), -1);
+        best[0] = 0;
+        for (int x = 0; x < 8; ++x)
+            for (int t = 0; t <= n_tiles; ++t) {
+                const int cur = best[(size_t)x * (n_tiles + 1) + t];
+                if (cur == INF) continue;
+                for (int R = 16; R <= 31 && t + R <= n_tiles; ++R) {
+                    const int left = n_tiles - t - R;
+                    if (left < 16 * (7 - x) || left > 31 * (7 - x)) continue;
+                    const int v = std::max(cur, head_len(t, R));
+                    int& slot_ = best[(size_t)(x + 1) * (n_tiles + 1) + t + R];
+                    if (v < slot_) { slot_ = v; from[(size_t)(x + 1) * (n_tiles + 1) + t + R] = t; }
+                }
+            }
+        if (best[(size_t)8 * (n_tiles + 1) + n_tiles] == INF) return false;
+        int t = n_tiles;
+        for (int x = 8; x > 0; --x) {
+            const int f = from[(size_t)x * (n_tiles + 1) + t];
+            w.t0[x - 1] = (uint8_t)f;
+            w.R[x - 1] = (uint8_t)(t - f);
+            t = f;
+        }
+    }
+    for (int xcd = 0; xcd < 8; ++xcd) {
+        const int tile0 = w.t0[xcd];
+        const int R = w.R[xcd], T = Wg - R;
+        if (R < 16 || T < 1 || T > 16) return false;
+        int nkmax = 0;
+        for (int u = 0; u < R; ++u) nkmax = std::max<int>(nkmax, nk[tile0 + u]);
+        auto rem_of = [&](int h) { int64_t r = 0; for (int u = 0; u < R; ++u) r += std::max(0, (int)nk[tile0 + u] - h); return r; };
+        int h = nkmax;
+        for (int c = 0; c <= nkmax; ++c)
+            if ((int64_t)100 * c * T >= (int64_t)sigma * rem_of(c)) { h = c; break; }
+        const int64_t rem = rem_of(h);
+        if (h < 1 || rem > 65535) return false;
+        const int pt = rem > 0 ? (int)((rem + T - 1) / T) : 0;
+        w.h[xcd] = (uint16_t)h; w.pt[xcd] = (uint16_t)pt; w.rem[xcd] = (uint16_t)rem;
+        int64_t P = 0;
+        for (int u = 0; u < R; ++u) {
+            const int r = std::max(0, (int)nk[tile0 + u] - h);
+            w.P[tile0 + u] = (uint16_t)P;
+            if (r > 0 && (P + r - 1) / pt - P / pt > 2) return false;      // more than three parts
+            P += r;
+        }
+        for (int j = 0; j < 16; ++j) {
+            w.first[xcd][j] = 0;
+            if (j >= T || pt == 0) continue;
+            const int64_t lo = (int64_t)j * pt;
+            for (int u = 0; u < R; ++u) {
+                const int r = std::max(0, (int)nk[tile0 + u] - h);
+                if (r > 0 && w.P[tile0 + u] + r > lo) { w.first[xcd][j] = (uint8_t)u; break; }
+            }
+        }
+    }
+    return true;
+}
 __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_all, int seg) {
+    if (sk.wt) {
+        typedef const __attribute__((address_space(4))) StreamKW* wptr;
+        return streamk_plan_w((wptr)sk.wt, sk.n_tiles, (int)blockIdx.x, (int)gridDim.x, seg);
+    }
     return streamk_plan(sk.n_tiles, nk_all, (int)blockIdx.x, (int)gridDim.x, seg, sk.sigma);
 }
 
@@ -1189,10 +1367,16 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
         if (d.nk == 0) return false;
         tile = d.tile; kb = d.kb; nk = d.nk;
+        if constexpr (SrcA::KPERM) {                 // (the tile's tap list; its K-tile count is what the weighted plan was built from)
+            sa.set_tile((grid_m < 0 ? tile % gm_t : tile / gn_t) * TM);
+        }
     } else {
         const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = bx % 8;
         tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + bx / 8;
         int64_t nk_tile = nk_all;
+        if constexpr (SrcA::KPERM) {                 // conv forward / input gradient in position-major row order: the tile's taps
+            nk_tile = sa.set_tile((grid_m < 0 ? tile % gm_t : tile / gn_t) * TM);
+        }
         if constexpr (SrcB::NPERM) {                 // conv weight gradient in position-major row order: only the K-tiles its tap stays inside for
             if (sb.tpp) {
                 const int64_t bn_ = grid_m < 0 ? tile / gm_t : tile % gn_t;
@@ -1472,11 +1656,13 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
         // ever waits for workgroups that were dispatched before it; other kernels sharing the chip can delay the tails but not
         // starve them.  tests/test_host_cpu.py checks on the plan that every publisher has a lower block index than its owner.
         for (int part = 0; part < d.parts; ++part) {
-            const int sl = 2 * d.tile + part;
+            const int sl = d.slot + part;
             if (tid2 == 0) {
                 // (relaxed polls: an ACQUIRE load at agent scope invalidates the XCD's L2 on EVERY poll - under the tails that are
                 //  still streaming their operand panels through it; the one acquire fence below orders the reads of the slot)
-                while (__hip_atomic_load(sk.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+                // (bounded: ~2 s.  A plan error would otherwise hang the GPU; this way it ends as a wrong result that the tests see)
+                for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(sk.flags + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+                    __builtin_amdgcn_s_sleep(16);
                 __hip_atomic_store(sk.flags + sl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
@@ -1557,13 +1743,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(SrcA sa, SrcB sb, Epilogue<T
 
 // Stream-K launch: all arguments in ONE struct, read afresh from the kernarg segment (scalar loads through a pointer the
 // compiler cannot see through) at the top of every segment, so that nothing but the segment counter lives across a segment.
-template <typename TC, typename SrcA, typename SrcB> struct G8SkArgs {
+template <typename TC, typename SrcA, typename SrcB> struct G8SkCore {
     SrcA sa;
     SrcB sb;
     Epilogue<TC> ep;
     int64_t M, N, K;
     int grid_m;
     StreamK sk;
+    int weighted;            // G8SkArgs::wt holds the weighted plan's tables
+};
+template <typename TC, typename SrcA, typename SrcB> struct G8SkArgs {
+    G8SkCore<TC, SrcA, SrcB> core;
+    StreamKW wt;             // (never copied into registers: read in place with scalar loads)
 };
 template <typename TC, typename SrcA, typename SrcB>
 __global__ __launch_bounds__(512) void gemm8_sk_kernel(G8SkArgs<TC, SrcA, SrcB> unused_by_name) {
@@ -1573,8 +1764,10 @@ __global__ __launch_bounds__(512) void gemm8_sk_kernel(G8SkArgs<TC, SrcA, SrcB> 
     for (int seg = 0; seg < 64; ++seg) {
         karg_ptr p = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(p));
-        const G8SkArgs<TC, SrcA, SrcB> a = *p;
-        if (!gemm8_body<TC, SrcA, SrcB, true>(a.sa, a.sb, a.ep, a.M, a.N, a.K, a.grid_m, a.sk, (int)blockIdx.x, 0, (int)gridDim.x, 1, seg)) break;
+        const G8SkCore<TC, SrcA, SrcB> a = p->core;
+        StreamK sk = a.sk;
+        if (a.weighted) sk.wt = (const void*)&p->wt;            // (stays kernel-argument memory: streamk_segment reads it with scalar loads)
+        if (!gemm8_body<TC, SrcA, SrcB, true>(a.sa, a.sb, a.ep, a.M, a.N, a.K, a.grid_m, sk, (int)blockIdx.x, 0, (int)gridDim.x, 1, seg)) break;
     }
 #endif
 }
@@ -1603,7 +1796,7 @@ __global__ __launch_bounds__(512) void gemm8_group_kernel(G8Group<TC, SrcA, SrcB
     const G8Entry<TC, SrcA, SrcB>& e = grp.e[p];
     const int local = (int)blockIdx.x - e.first;
     if (local >= e.tiles * e.split) return;                    // padding of the range up to a multiple of 8
-    gemm8_body<TC, SrcA, SrcB, false>(e.sa, e.sb, e.ep, e.M, e.N, e.K, e.grid_m, StreamK{nullptr, nullptr, 0, 100}, e.tile0 + local % e.tiles,
+    gemm8_body<TC, SrcA, SrcB, false>(e.sa, e.sb, e.ep, e.M, e.N, e.K, e.grid_m, StreamK{nullptr, nullptr, 0, 100, nullptr}, e.tile0 + local % e.tiles,
                                       local / e.tiles, e.total, e.split);
 }
 
@@ -1612,7 +1805,7 @@ __global__ __launch_bounds__(512) void gemm8_group_kernel(G8Group<TC, SrcA, SrcB
 // the launches of ONE stream at a time (launches on a stream are ordered; two streams could overlap and need one each).
 constexpr size_t STREAMK_FLAG_BYTES = 4096;
 static StreamK streamk_view(void* ws) {
-    StreamK sk{nullptr, nullptr, 0, 100};
+    StreamK sk{nullptr, nullptr, 0, 100, nullptr};
     if (ws) {
         sk.flags = reinterpret_cast<int*>(ws);
         sk.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + STREAMK_FLAG_BYTES);
@@ -1654,8 +1847,32 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
                 raise_lds_limit(raised_sk, reinterpret_cast<const void*>(kern), (int)lds);
                 sk.n_tiles = (int)tiles;
                 sk.sigma = (int)sg;
+                G8SkArgs<TC, SrcA, SrcB> args{{sa, sb, ep, M, N, K, tile_order(gm, gn), sk, 0}, {}};
+                if constexpr (SrcA::KPERM) {
+                    if (sa.g.rpp) {                  // position-major rows: tiles of different length -> the weighted plan
+                        uint16_t nkt[256];
+                        const int go = args.core.grid_m;
+                        const int64_t gm_t = go < 0 ? -go : go, gn_t = tiles / gm_t;
+                        for (int64_t t = 0; t < tiles; ++t) {
+                            const int64_t bm = go < 0 ? t % gm_t : t / gn_t;
+                            const uint32_t m9 = conv_tile_mask9(bm * 256, M, sa.g.rpp, sa.g.Hp - 2, sa.g.Wp - 2);
+                            nkt[t] = (uint16_t)(5 * __builtin_popcount(m9) * (sa.g.Cin / 64));
+                        }
+                        // (the tables depend on the shape only: built once per shape and thread, ~2 ms of host time)
+                        static thread_local std::vector<uint16_t> key;
+                        static thread_local StreamKW cached;
+                        static thread_local int cached_ok = 0, cached_sigma = 0;
+                        if (key.size() != (size_t)tiles || cached_sigma != (int)sg || !std::equal(key.begin(), key.end(), nkt)) {
+                            key.assign(nkt, nkt + tiles);
+                            cached_sigma = (int)sg;
+                            cached_ok = streamk_w_build(cached, (int)tiles, nkt, (int)sg) ? 1 : 0;
+                        }
+                        if (cached_ok) { args.wt = cached; args.core.weighted = 1; }
+                        else args.core.sa.g.rpp = 0; // (no weighted plan for these lengths: every tap for every tile, the uniform plan)
+                    }
+                }
                 g_streamk_launches.fetch_add(1, std::memory_order_relaxed);
-                hipLaunchKernelGGL(kern, dim3(STREAMK_WGS), dim3(512), lds, st, G8SkArgs<TC, SrcA, SrcB>{sa, sb, ep, M, N, K, tile_order(gm, gn), sk});
+                hipLaunchKernelGGL(kern, dim3(STREAMK_WGS), dim3(512), lds, st, args);
                 return check_launch(what);
             }
         }
@@ -1671,7 +1888,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
             static std::atomic<uint64_t> raised192{0};
             raise_lds_limit(raised192, reinterpret_cast<const void*>(kern), (int)lds);
             hipLaunchKernelGGL(kern, dim3((unsigned)tiles192, 1), dim3(512), lds, st, sa, sb, ep, M, N, K,
-                               tile_order(gm192, gn), StreamK{nullptr, nullptr, 0, 100});
+                               tile_order(gm192, gn), StreamK{nullptr, nullptr, 0, 100, nullptr});
             return check_launch(what);
         }
     }
@@ -1680,7 +1897,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
     raise_lds_limit(raised, reinterpret_cast<const void*>(kern), (int)lds);
     if (split > 1) ep.atomic = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, split), dim3(512), lds, st, sa, sb, ep, M, N, K,
-                       tile_order(gm, gn), StreamK{nullptr, nullptr, 0, 100});
+                       tile_order(gm, gn), StreamK{nullptr, nullptr, 0, 100, nullptr});
     return check_launch(what);
 }
 
@@ -1781,7 +1998,8 @@ __global__ void conv_pos_kernel(int32_t* pos_in, int32_t* pos_out, int B, int Ti
 // Row order 1 (position-major): row r = ((h W + w) B + b) To + to.  Same tables for that order, plus std2row[m] = r for the
 // standard row m = ((b To + to) H + h) W + w (a producer that computes rows in standard order - the next convolution's input
 // gradient - writes them where this order expects them).
-__global__ void conv_pos_grouped_kernel(int32_t* pos_in, int32_t* pos_out, int32_t* std2row, int B, int Tin, int To, int H, int W) {
+__global__ void conv_pos_grouped_kernel(int32_t* pos_in, int32_t* pos_out, int32_t* std2row, int32_t* row2std, int B, int Tin, int To, int H,
+                                        int W) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t M = (int64_t)B * To * H * W;
     if (m >= M) return;
@@ -1791,6 +2009,7 @@ __global__ void conv_pos_grouped_kernel(int32_t* pos_in, int32_t* pos_out, int32
     pos_in[r] = (int32_t)((((int64_t)b * Tin + to) * Hp + h) * Wp + w);
     pos_out[r] = (int32_t)((((int64_t)b * To + to) * Hp + h + 1) * Wp + w + 1);
     std2row[m] = (int32_t)r;
+    row2std[r] = (int32_t)m;
 }
 
 // [B,C,T,H,W] fp32 -> [B,T,H+2,W+2,C] (T) with a zero border.  LDS-tiled transpose: a block moves a
@@ -1984,6 +2203,20 @@ extern "C" int shg_streamk_plan(int n_tiles, int nk, int block, int seg, int* ou
     return d.nk > 0 ? 1 : 0;
 }
 
+// the weighted plan on the host: nk_tile[n_tiles] K-tiles per tile -> the same descriptor; -1: no weighted plan for these lengths
+extern "C" int shg_streamk_plan_weighted(int n_tiles, const uint16_t* nk_tile, int block, int seg, int* out) {
+    if (!out || !nk_tile || n_tiles < 128 || n_tiles >= 256 || block < 0 || block >= shg::STREAMK_WGS || seg < 0) return shg::fail_arg("streamk_plan_weighted: bad argument");
+    static thread_local shg::StreamKW w;
+    static thread_local std::vector<uint16_t> cached;
+    if (cached.size() != (size_t)n_tiles || !std::equal(cached.begin(), cached.end(), nk_tile)) {
+        cached.assign(nk_tile, nk_tile + n_tiles);
+        if (!shg::streamk_w_build(w, n_tiles, nk_tile, shg::streamk_sigma())) { cached.clear(); return -1; }
+    }
+    const shg::StreamKSeg d = shg::streamk_plan_w((const shg::StreamKW*)&w, n_tiles, block, shg::STREAMK_WGS, seg);
+    out[0] = d.tile; out[1] = d.kb; out[2] = d.nk; out[3] = d.owner; out[4] = d.slot; out[5] = d.parts;
+    return d.nk > 0 ? 1 : 0;
+}
+
 extern "C" int64_t shg_gemm_streamk_launches(void) { return shg::g_streamk_launches.load(std::memory_order_relaxed); }
 
 extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
@@ -2072,7 +2305,7 @@ extern "C" int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int
 extern "C" int64_t shg_conv3d_k533_workspace_bytes_ex(int B, int T, int H, int W, int row_order) {
     const int64_t two = shg_conv3d_k533_workspace_bytes(B, T, H, W);
     if (two < 0 || row_order < 0 || row_order > 1) return -1;
-    return row_order ? two / 2 * 3 : two;
+    return row_order ? two * 2 : two;
 }
 
 extern "C" int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, int W, int row_order, void* stream) {
@@ -2082,8 +2315,9 @@ extern "C" int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, 
     int32_t* pos_in = (int32_t*)workspace;
     int32_t* pos_out = (int32_t*)((char*)workspace + seg);
     int32_t* std2row = (int32_t*)((char*)workspace + 2 * seg);
-    hipLaunchKernelGGL(conv_pos_grouped_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_in, pos_out, std2row, B,
-                       T, T - 4, H, W);
+    int32_t* row2std = (int32_t*)((char*)workspace + 3 * seg);
+    hipLaunchKernelGGL(conv_pos_grouped_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_in, pos_out, std2row,
+                       row2std, B, T, T - 4, H, W);
     return check_launch("conv3d_prepare_ex");
 }
 
@@ -2101,13 +2335,16 @@ extern "C" int shg_streamk_workspace_init(void* ws, void* stream) {
 extern "C" int shg_conv3d_k533_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
                                    int H, int W, int Cin, int Cout, int act, int pad_out, void* y_pre,
                                    const void* workspace, void* streamk_ws, void* stream) {
-    return shg_conv3d_k533_fwd_rows(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, nullptr, workspace, streamk_ws, stream);
+    return shg_conv3d_k533_fwd_rows(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, nullptr, nullptr, 0, workspace, streamk_ws, stream);
 }
 
 extern "C" int shg_conv3d_k533_fwd_rows(const void* x, const void* w, const float* bias, void* y, int dtype, int B, int T,
                                         int H, int W, int Cin, int Cout, int act, int pad_out, void* y_pre, const int32_t* pre_rows,
-                                        const void* workspace, void* streamk_ws, void* stream) {
-    SHG_REPEAT(64, shg_conv3d_k533_fwd_rows(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, pre_rows, workspace, streamk_ws, stream));
+                                        const int32_t* y_rows, int row_order, const void* workspace, void* streamk_ws, void* stream) {
+    SHG_REPEAT(64, shg_conv3d_k533_fwd_rows(x, w, bias, y, dtype, B, T, H, W, Cin, Cout, act, pad_out, y_pre, pre_rows, y_rows, row_order, workspace,
+                                            streamk_ws, stream));
+    if (row_order < 0 || row_order > 1) return fail_arg("conv3d_fwd_rows: row_order must be 0 or 1");
+    if (pad_out && y_rows) return fail_arg("conv3d_fwd_rows: y_rows is for the dense output (pad_out = 0)");
     if (!x || !w || !y) return fail_arg("conv3d_fwd: null pointer");
     if (streamk_ws && !al16(streamk_ws)) return fail_arg("conv3d_fwd: streamk workspace must be 16-byte aligned");
     if (y_pre && !al16(y_pre)) return fail_arg("conv3d_fwd: y_pre must be 16-byte aligned");
@@ -2117,16 +2354,21 @@ extern "C" int shg_conv3d_k533_fwd_rows(const void* x, const void* w, const floa
     const int32_t* pos_in = (const int32_t*)workspace;
     const int32_t* pos_out = (const int32_t*)((const char*)workspace + shg_conv3d_k533_workspace_bytes(B, T, H, W) / 2);
     ConvGeom g = conv_geom(Cin, H + 2, W + 2);
+    // position-major rows (the caller's tables are of row order 1): a tile drops the taps that read only the zero border for all of
+    // its rows ("conv_k_order" bit 5; needs the channel-block-major K order and the stream-K launch's weighted plan to pay)
+    if (row_order == 1 && g.kperm && dtype == SHG_BF16 && (tuning(TUNE_CONV_K_ORDER) & 32) && (int64_t)45 * (Cin / 64) < 4000) {
+        g.rpp = B * (T - 4);
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SHG_F32) {
         ConvRowSrc<float, 256> sa{(const float*)x, pos_in, 0, M, g};
         PlainSrc<float, true> sb{(const float*)w, K, 0, N, K};
-        Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (float*)y_pre, 0};
+        Epilogue<float> ep{(float*)y, Cout, bias, pad_out ? pos_out : y_rows, act, 0, 1, (float*)y_pre, 0};
         ep.prow = pre_rows;
         return launch_cfg<float, float, decltype(sa), decltype(sb), 2, 2, 2, 2>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);
     }
     PlainSrc<bf16_t, true> sb{(const bf16_t*)w, K, 0, N, K};
-    Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : nullptr, act, 0, 1, (bf16_t*)y_pre, 0};
+    Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : y_rows, act, 0, 1, (bf16_t*)y_pre, 0};
     ep.prow = pre_rows;
     if (use_gemm8(M, N, K, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2, N * K * 2)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};

@@ -100,6 +100,9 @@ class Engine:
         # row order of the first convolution's GEMM rows (ops.conv1_forward and its backward): 1 = position-major, with which the
         # weight gradient skips the zero-border positions of every tap (include/shg_vqa.h, shg_conv3d_k533_wgrad_ex)
         self.conv1_row_order = int(os.environ.get("SHG_CONV1_ROW_ORDER", "1"))
+        # the conv FORWARDS in position-major rows too: tiles leave out the taps that read only the zero border, the stream-K launch
+        # balances their different lengths with its weighted plan ("conv_k_order" bit 5)
+        self.conv_fwd_pm = int(os.environ.get("SHG_CONV_FWD_PM", "1"))
         self.norm_extra = None
         self.overwritten, self.unzeroed = {}, {}
         self.overwrite_poisoned = False

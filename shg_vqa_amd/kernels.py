@@ -460,8 +460,15 @@ def conv_workspace(B, T, H, W, device, order=0):
 def conv_row_table(B, T, H, W, device):
     """int32 [B (T-4) H W]: position-major row of every standard row (the third table of the order-1 workspace)."""
     ws = conv_workspace(B, T, H, W, device, 1)
-    seg = ws.numel() // 3
-    return ws[2 * seg:].view(torch.int32)[:B * (T - 4) * H * W]
+    seg = ws.numel() // 4
+    return ws[2 * seg:3 * seg].view(torch.int32)[:B * (T - 4) * H * W]
+
+
+def conv_row_table_inv(B, T, H, W, device):
+    """int32 [B (T-4) H W]: standard row of every position-major row (the fourth table)."""
+    ws = conv_workspace(B, T, H, W, device, 1)
+    seg = ws.numel() // 4
+    return ws[3 * seg:].view(torch.int32)[:B * (T - 4) * H * W]
 
 
 _streamk_ws = {}
@@ -483,7 +490,8 @@ def streamk_workspace(device):
     return ws
 
 
-def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None, order=0, pre_rows=None):
+def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, want_pre=False, pre_out=None, order=0, pre_rows=None,
+                    y_rows=None):
     """x_cl [B,T,H+2,W+2,Cin] (zero border); w_cl [Cout,5,3,3,Cin]; -> y [B,T-4,H,W,Cout]
     (or written into the interior of a zero-bordered [B,T-4,H+2,W+2,Cout] buffer when pad_out)."""
     _dev(x_cl, w_cl, bias, out)
@@ -506,8 +514,12 @@ def conv3d_k533_fwd(x_cl, w_cl, bias, act=ACT_NONE, pad_out=False, out=None, wan
     if pre_rows is not None:                      # row m of pre goes to row pre_rows[m] (e.g. conv_row_table: a standard-order forward, pre position-major)
         _dev(pre_rows)
         _need(pre_rows.dtype == torch.int32 and pre_rows.is_contiguous() and pre_rows.numel() == B * (T - 4) * H * W, "pre_rows must be int32 [rows]")
+    if y_rows is not None:                        # dense output row m goes to row y_rows[m]
+        _dev(y_rows)
+        _need(not pad_out and y_rows.dtype == torch.int32 and y_rows.is_contiguous() and y_rows.numel() == B * (T - 4) * H * W,
+              "y_rows: int32 [rows], dense output only")
     _lib.call("shg_conv3d_k533_fwd_rows", x_cl.data_ptr(), w_cl.data_ptr(), _p(bias), out.data_ptr(), _dt(x_cl), B, T, H, W, cin,
-              cout, act, 1 if pad_out else 0, _p(pre), _p(pre_rows), ws.data_ptr(), _p(sk), _stream())
+              cout, act, 1 if pad_out else 0, _p(pre), _p(pre_rows), _p(y_rows), int(order), ws.data_ptr(), _p(sk), _stream())
     return (out, pre) if want_pre else out
 
 

@@ -451,8 +451,13 @@ def conv1_forward(feat, w1, b1, bufs=None):
     # (E.conv1_row_order = 1: the BACKWARD works on position-major rows - the weight gradient then skips the zero-border positions
     #  of every tap.  The forward keeps the standard row order (neighbouring rows share input lines: 3-5 % faster) and writes the
     #  pre-activation it saves for backward through the row table; y1p is a layout and does not depend on the order)
-    rows = K.conv_row_table(B, T, H, W, feat.device) if E.conv1_row_order else None
-    K.conv3d_k533_fwd(x_cl, E.operand(w1), b1._shg_store, ACT_GELU, pad_out=True, out=y1p, want_pre=True, pre_out=pre1, pre_rows=rows)
+    #  E.conv_fwd_pm: the forward itself in position-major rows, where a tile leaves out the taps that read only the zero border
+    #  (the stream-K launch's weighted plan, "conv_k_order" bit 5))
+    if E.conv1_row_order and E.conv_fwd_pm:
+        K.conv3d_k533_fwd(x_cl, E.operand(w1), b1._shg_store, ACT_GELU, pad_out=True, out=y1p, want_pre=True, pre_out=pre1, order=1)
+    else:
+        rows = K.conv_row_table(B, T, H, W, feat.device) if E.conv1_row_order else None
+        K.conv3d_k533_fwd(x_cl, E.operand(w1), b1._shg_store, ACT_GELU, pad_out=True, out=y1p, want_pre=True, pre_out=pre1, pre_rows=rows)
     if evs is not None:
         e1.record()
         evs.append((e0, e1))
@@ -505,8 +510,13 @@ class _VisualConvTokens(torch.autograd.Function):
         cdt = E.compute_dtype
         # (as for conv1: forward in standard row order, the saved pre-activation in the position-major rows its backward works on)
         ctx.order2 = E.conv1_row_order
-        rows2 = K.conv_row_table(y1p.shape[0], y1p.shape[1], y1p.shape[2] - 2, y1p.shape[3] - 2, y1p.device) if ctx.order2 else None
-        y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True, pre_rows=rows2)
+        shp = (y1p.shape[0], y1p.shape[1], y1p.shape[2] - 2, y1p.shape[3] - 2, y1p.device)
+        if ctx.order2 and E.conv_fwd_pm:               # position-major forward (tap skipping), the token rows back in sequence order
+            y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True, order=1,
+                                         y_rows=K.conv_row_table_inv(*shp))
+        else:
+            rows2 = K.conv_row_table(*shp) if ctx.order2 else None
+            y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True, pre_rows=rows2)
         B = x_cl.shape[0]
         C = y2.shape[-1]
         out = K.tokens_assemble(y2.view(B, -1, C), cls_token._shg_store.view(-1), pe._shg_store)     # cls + positions, one kernel

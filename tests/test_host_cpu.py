@@ -222,6 +222,81 @@ def test_streamk_plan_covers_every_k_tile_exactly_once():
         assert len(busy) == 256 and max(busy) <= 1.07 * sigma / 100 * n_tiles * nk / 256, (n_tiles, nk, min(busy), max(busy))
 
 
+def test_weighted_streamk_plan_covers_tiles_of_different_length():
+    """The weighted stream-K split (gemm.hip: streamk_plan_w / streamk_w_build through shg_streamk_plan_weighted): the conv forwards in
+    position-major row order, whose tiles keep 20 / 30 / 40 / 45 of the 45 taps.  Same checks as for the uniform plan: exact cover of
+    every tile's own K range, one owner per tile expecting exactly the published parts (at most three, slots 3 tile + part), tails
+    before heads in every XCD (the no-deadlock argument), and no workgroup far above the even share."""
+    import ctypes
+    import math
+    from shg_vqa_amd import _lib
+    lib = _lib.lib()
+    out = (ctypes.c_int * 6)()
+    sigma = min(200, max(100, int(os.environ.get("SHG_STREAMK_SIGMA", "112"))))
+
+    def valid9(p, H=7, W=7):
+        h, w = divmod(p, W)
+        return {(kh, kw) for kh in range(3) for kw in range(3) if 0 <= h + kh - 1 < H and 0 <= w + kw - 1 < W}
+
+    def tile_lengths(M, rpp, cin, gn, m_fastest):
+        gm = math.ceil(M / 256)
+        per_m = []
+        for bm in range(gm):
+            taps = set()
+            for p in range(bm * 256 // rpp, min(M - 1, bm * 256 + 255) // rpp + 1):
+                taps |= valid9(p)
+            per_m.append(5 * len(taps) * (cin // 64))
+        return [per_m[t % gm] if m_fastest else per_m[t // gn] for t in range(gm * gn)]
+
+    cases = [(tile_lengths(18816, 384, 2048, 3, False), 1.13), (tile_lengths(18816, 384, 2048, 3, True), 1.20),   # conv1: 222 tiles, 640 .. 1 440
+             (tile_lengths(12544, 256, 768, 3, False), 1.13), (tile_lengths(12544, 256, 768, 3, True), 1.20),    # conv2: 147 tiles, 240 .. 540
+             ([100 + (7 * t) % 50 for t in range(200)], 1.10), ([300] * 180, 1.08)]
+    for nk, slack in cases:
+        n_tiles = len(nk)
+        arr = (ctypes.c_uint16 * n_tiles)(*nk)
+
+        def plan(block, seg):
+            rc = lib.shg_streamk_plan_weighted(n_tiles, arr, block, seg, out)
+            assert rc in (0, 1), rc
+            return tuple(out) if rc else None
+
+        cover = [[] for _ in range(n_tiles)]
+        owners, expected_parts, published, work, first_head = {}, {}, {}, [], {}
+        for block in range(256):
+            xcd, total = block & 7, 0
+            for seg in range(64):
+                d = plan(block, seg)
+                if d is None:
+                    break
+                tile, kb, n, owner, slot, parts = d
+                assert 0 <= tile < n_tiles and n > 0 and 0 <= kb and kb + n <= nk[tile], (d, nk[tile])
+                cover[tile].append((kb, kb + n))
+                total += n
+                if owner:
+                    assert tile not in owners and kb == 0 and seg == 0 and slot == 3 * tile and 0 <= parts <= 3
+                    owners[tile] = block
+                    expected_parts[tile] = parts
+                    first_head.setdefault(xcd, block)
+                else:
+                    assert 3 * tile <= slot < 3 * tile + 3 and slot not in published and slot < 768
+                    published[slot] = block
+                    assert xcd not in first_head, "a tail workgroup after a head of its XCD"
+            work.append(total)
+        for tile, ranges in enumerate(cover):
+            ranges.sort()
+            assert ranges[0][0] == 0 and ranges[-1][1] == nk[tile], (tile, ranges, nk[tile])
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), (tile, ranges)
+        assert sorted(owners) == list(range(n_tiles))
+        for tile, parts in expected_parts.items():
+            got = [s for s in range(3 * tile, 3 * tile + 3) if s in published]
+            assert got == [3 * tile + p for p in range(parts)], (tile, parts, got)
+            for s_ in got:
+                assert published[s_] & 7 == owners[tile] & 7 and published[s_] < owners[tile]
+        busy = [w for w in work if w]
+        print(n_tiles, "workgroups busy", len(busy), "min / max / mean K-tiles", min(busy), max(busy), sum(nk) / 256)
+        assert len(busy) >= 250 and max(busy) <= slack * sigma / 100 * sum(nk) / 256, (n_tiles, min(busy), max(busy), sum(nk) / 256)
+
+
 def test_bench_constants_follow_the_survey_flop_table():
     """bench.py prices its fractions with SURVEY section 8(d): 428.21 / 178.79 / 45.50 GFLOP per QA pair (training, forward, the
     attention stack's forward) and conv1 = 83.236 GFLOP per QA pair = 2 x (12 x 49) x 768 x (45 x 2048) flop."""

@@ -1046,6 +1046,18 @@ def test_conv_forward_at_bench_shape_streamk_integer_exact_and_bf16_rows(K, name
     y = K.conv3d_k533_fwd(xi.bfloat16(), wi.bfloat16(), bi, act=0)
     torch.cuda.synchronize()
     assert torch.equal(y.view(-1, Cout), ref), (y.view(-1, Cout).float() - ref.float()).abs().max()
+    # position-major rows: tiles drop the taps that read only the zero border, the stream-K launch runs its WEIGHTED plan
+    # ("conv_k_order" bit 5); dense output back in standard order through the row table - the same integers
+    inv = K.conv_row_table_inv(B, T, H, W, DEV)
+    for sw in (62, 30):
+        _lib.set_tuning("conv_k_order", sw)
+        try:
+            y_pm = K.conv3d_k533_fwd(xi.bfloat16(), wi.bfloat16(), bi, act=0, order=1, y_rows=inv)
+            torch.cuda.synchronize()
+            assert torch.equal(y_pm.view(-1, Cout), ref), (sw, (y_pm.view(-1, Cout).float() - ref.float()).abs().max())
+        finally:
+            _lib.set_tuning("conv_k_order", 62)
+    before += 2
     del ref, xi, wi
     # (ii) random data, sampled rows, GELU epilogue + pre-activation output as in the step
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
@@ -1123,7 +1135,7 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
             assert torch.equal(dw.view(Cout, -1), ref), skip
             assert abs(ss.item() - want) <= 1e-6 * want, (skip, ss.item(), want)
         finally:
-            _lib.set_tuning("conv_k_order", 30)
+            _lib.set_tuning("conv_k_order", 62)
     del ref, xi, dyi, dy_pm
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
     xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
