@@ -348,7 +348,7 @@ def main():
             row_w["executed_flop_per_launch"] = conv1_flop * 361.0 / 441.0
             row_w["executed_tflops"] = round(achieved_w * 361.0 / 441.0, 2)
             row_w["note"] = "zero-border products skipped (DESIGN.md section 9 (10)): executed flop = 361/441 of the algorithmic count"
-        if getattr(E, "conv1_row_order", 0) == 1 and getattr(E, "conv_fwd_pm", 0) and B == 32:
+        if getattr(E, "conv1_row_order", 0) == 1 and (getattr(E, "conv_fwd_pm", 0) & 1) and B == 32:
             # forward in position-major rows: a 256-row tile leaves out the (kh, kw) taps that read only the zero border for all of its
             # rows - 562 of the 666 (tile, kh, kw) pairs of the 74 row blocks remain (B = 32: 384 rows per position)
             row_f["executed_flop_per_launch"] = conv1_flop * 562.0 / 666.0

@@ -62,6 +62,7 @@ template <typename T, bool KMAJ> struct PlainSrc {
     static constexpr bool KMAJOR = KMAJ;
     static constexpr bool KPERM = false;
     static constexpr bool NPERM = false;
+    static constexpr bool SKIP = false;
     __device__ __forceinline__ int64_t k_of_tile(int64_t kt) const { return kt * 64; }
     const T* p;
     int64_t ld, r0, R, K;
@@ -159,8 +160,10 @@ __host__ __device__ __forceinline__ uint32_t conv_tile_mask9(int64_t m0, int64_t
 }
 
 // A operand of the conv forward: rows = output positions (gathered), K = (tap, channel), K contiguous.
-template <typename T, int NTHR> struct ConvRowSrc {
+template <typename T, int NTHR, bool SKIP_ = false> struct ConvRowSrc {
     static constexpr bool KMAJOR = true;
+    static constexpr bool SKIP = SKIP_;      // the instantiation with per-tile tap lists (position-major forward); the plain one keeps
+                                             // its registers: 92 against 156 bytes of scratch per lane in the stream-K kernel
     // K = (tap, channel) is a sum: its 64-wide tiles may be visited in any order as long as BOTH operands follow it.  Tap-major (the
     // storage order) re-reads every input line 45 times with a whole sweep over the channels (an XCD's ~10 row panels x Cin x 2 B,
     // 10 MB at 2 048 channels) between two uses: each of them misses the 4 MB L2.  Channel-block-major (g.kperm) keeps the 45 uses
@@ -171,7 +174,7 @@ template <typename T, int NTHR> struct ConvRowSrc {
     // only the zero border for every one of them.  set_tile: the tile's list of taps - n9 of the 9 (kh, kw), their numbers as
     // nibbles - and the K-tiles it leaves: 5 n9 taps x Cin / 64.  g.rpp == 0 (any row order): all 45.
     __device__ __forceinline__ int set_tile(int64_t m0) {
-        if (!g.rpp) return 45 * (g.Cin >> 6);
+        if (!SKIP || !g.rpp) return 45 * (g.Cin >> 6);
         const uint32_t mask = conv_tile_mask9(m0, M, g.rpp, g.Hp - 2, g.Wp - 2);
         uint64_t nb = 0;
         uint32_t c = 0;
@@ -187,6 +190,11 @@ template <typename T, int NTHR> struct ConvRowSrc {
         // blocks of nb = 2^(kperm-1) K-tiles (64 nb channels): tile kt = (block, tap, tile in block).  Branch-free (a branch inside the
         // 8-phase loop splits its phases into basic blocks the scheduler cannot interleave across: +8-24 % per launch, measured)
         const uint32_t sh = (uint32_t)max(g.kperm - 1, 0), k = (uint32_t)kt, q = k >> sh, sub = k - (q << sh);
+        if constexpr (!SKIP) {
+            const uint32_t blk = (q * 11651u) >> 19, tap = q - blk * 45u;             // q / 45 for q < 20 000
+            const uint32_t kp = tap * (uint32_t)g.Cin + (((blk << sh) + sub) << 6);
+            return (int64_t)(g.kperm ? kp : k << 6);
+        }
         // q / ntaps, then the tap's place in the tile's list -> its number (x / d == (x * ((1 << 20) / d + 1)) >> 20 for x < 4 095)
         const uint32_t blk = (q * ntaps_magic) >> 20, j = q - blk * ntaps;
         const uint32_t k3 = (j * n9_magic) >> 20, s9 = j - k3 * n9;
@@ -1313,8 +1321,9 @@ static bool streamk_w_build(StreamKW& w, int n_tiles, const uint16_t* nk, int si
     }
     return true;
 }
+template <bool WEIGHTED>
 __device__ __forceinline__ StreamKSeg streamk_segment(const StreamK& sk, int nk_all, int seg) {
-    if (sk.wt) {
+    if (WEIGHTED && sk.wt) {
         typedef const __attribute__((address_space(4))) StreamKW* wptr;
         return streamk_plan_w((wptr)sk.wt, sk.n_tiles, (int)blockIdx.x, (int)gridDim.x, seg);
     }
@@ -1364,17 +1373,17 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     if constexpr (SK) {
         int s_ = seg;
         asm volatile("" : "+s"(s_));
-        const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
+        const StreamKSeg d = streamk_segment<SrcA::SKIP>(sk, (int)nk_all, s_);
         if (d.nk == 0) return false;
         tile = d.tile; kb = d.kb; nk = d.nk;
-        if constexpr (SrcA::KPERM) {                 // (the tile's tap list; its K-tile count is what the weighted plan was built from)
+        if constexpr (SrcA::SKIP) {                  // (the tile's tap list; its K-tile count is what the weighted plan was built from)
             sa.set_tile((grid_m < 0 ? tile % gm_t : tile / gn_t) * TM);
         }
     } else {
         const int64_t xq = n_tiles / 8, xr = n_tiles % 8, xcd = bx % 8;
         tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + bx / 8;
         int64_t nk_tile = nk_all;
-        if constexpr (SrcA::KPERM) {                 // conv forward / input gradient in position-major row order: the tile's taps
+        if constexpr (SrcA::SKIP) {                  // conv forward in position-major row order: the tile's taps
             nk_tile = sa.set_tile((grid_m < 0 ? tile % gm_t : tile / gn_t) * TM);
         }
         if constexpr (SrcB::NPERM) {                 // conv weight gradient in position-major row order: only the K-tiles its tap stays inside for
@@ -1632,7 +1641,7 @@ __device__ __forceinline__ bool gemm8_body(SrcA sa, SrcB sb, Epilogue<TC> ep, in
     if constexpr (SK) {
         int s_ = seg;
         asm volatile("" : "+s"(s_));
-        const StreamKSeg d = streamk_segment(sk, (int)nk_all, s_);
+        const StreamKSeg d = streamk_segment<SrcA::SKIP>(sk, (int)nk_all, s_);
         if (!d.owner) {
             // tail segment: publish the raw accumulators (register r of thread t at float4 index r * 512 + t)
             f32x4* slot = reinterpret_cast<f32x4*>(sk.ws + (size_t)d.slot * STREAMK_SLOT) + tid2;
@@ -1848,7 +1857,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
                 sk.n_tiles = (int)tiles;
                 sk.sigma = (int)sg;
                 G8SkArgs<TC, SrcA, SrcB> args{{sa, sb, ep, M, N, K, tile_order(gm, gn), sk, 0}, {}};
-                if constexpr (SrcA::KPERM) {
+                if constexpr (SrcA::SKIP) {
                     if (sa.g.rpp) {                  // position-major rows: tiles of different length -> the weighted plan
                         uint16_t nkt[256];
                         const int go = args.core.grid_m;
@@ -2371,9 +2380,14 @@ extern "C" int shg_conv3d_k533_fwd_rows(const void* x, const void* w, const floa
     Epilogue<bf16_t> ep{(bf16_t*)y, Cout, bias, pad_out ? pos_out : y_rows, act, 0, 1, (bf16_t*)y_pre, 0};
     ep.prow = pre_rows;
     if (use_gemm8(M, N, K, (int64_t)B * T * (H + 2) * (W + 2) * Cin * 2, N * K * 2)) {
+        if (g.rpp) {                                 // the instantiation with per-tile tap lists (and the weighted stream-K plan)
+            ConvRowSrc<bf16_t, 512, true> sa{(const bf16_t*)x, pos_in, 0, M, g};
+            return launch8<bf16_t, decltype(sa), decltype(sb), 1>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", 1, streamk_ws);
+        }
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
         return launch8<bf16_t, decltype(sa), decltype(sb), 1>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", 1, streamk_ws);
     }
+    g.rpp = 0;                                       // (the other kernels run every tap)
     if (use_large(1, M, N, K)) {
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)x, pos_in, 0, M, g};
         return launch_cfg<bf16_t, bf16_t, decltype(sa), decltype(sb), 4, 4, 2, 4>(sa, sb, ep, M, N, K, st, "conv3d_k533_fwd", false);

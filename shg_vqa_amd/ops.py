@@ -453,7 +453,7 @@ def conv1_forward(feat, w1, b1, bufs=None):
     #  pre-activation it saves for backward through the row table; y1p is a layout and does not depend on the order)
     #  E.conv_fwd_pm: the forward itself in position-major rows, where a tile leaves out the taps that read only the zero border
     #  (the stream-K launch's weighted plan, "conv_k_order" bit 5))
-    if E.conv1_row_order and E.conv_fwd_pm:
+    if E.conv1_row_order and (E.conv_fwd_pm & 1):
         K.conv3d_k533_fwd(x_cl, E.operand(w1), b1._shg_store, ACT_GELU, pad_out=True, out=y1p, want_pre=True, pre_out=pre1, order=1)
     else:
         rows = K.conv_row_table(B, T, H, W, feat.device) if E.conv1_row_order else None
@@ -511,7 +511,7 @@ class _VisualConvTokens(torch.autograd.Function):
         # (as for conv1: forward in standard row order, the saved pre-activation in the position-major rows its backward works on)
         ctx.order2 = E.conv1_row_order
         shp = (y1p.shape[0], y1p.shape[1], y1p.shape[2] - 2, y1p.shape[3] - 2, y1p.device)
-        if ctx.order2 and E.conv_fwd_pm:               # position-major forward (tap skipping), the token rows back in sequence order
+        if ctx.order2 and (E.conv_fwd_pm & 2):         # position-major forward (tap skipping), the token rows back in sequence order
             y2, pre2 = K.conv3d_k533_fwd(y1p, E.operand(w2), b2._shg_store, ACT_GELU, pad_out=False, want_pre=True, order=1,
                                          y_rows=K.conv_row_table_inv(*shp))
         else:

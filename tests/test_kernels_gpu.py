@@ -1058,6 +1058,19 @@ def test_conv_forward_at_bench_shape_streamk_integer_exact_and_bf16_rows(K, name
         finally:
             _lib.set_tuning("conv_k_order", 62)
     before += 2
+    # ... the same without the stream-K launch (one tile per workgroup, each with its own K-tile list)
+    _lib.set_tuning("streamk", 0)
+    try:
+        y_pm = K.conv3d_k533_fwd(xi.bfloat16(), wi.bfloat16(), bi, act=0, order=1, y_rows=inv)
+        assert torch.equal(y_pm.view(-1, Cout), ref)
+    finally:
+        _lib.set_tuning("streamk", 1)
+    # ... and at another batch size (24: 288 / 192 rows per position, other unions of taps per tile, another weighted plan)
+    B2 = 24
+    inv2 = K.conv_row_table_inv(B2, T, H, W, DEV)
+    y_pm = K.conv3d_k533_fwd(xi[:B2].bfloat16(), wi.bfloat16(), bi, act=0, order=1, y_rows=inv2)
+    assert torch.equal(y_pm.view(-1, Cout), ref[:B2 * To * H * W])
+    before += 1 if B2 * To * H * W // 256 * 3 >= 128 else 0
     del ref, xi, wi
     # (ii) random data, sampled rows, GELU epilogue + pre-activation output as in the step
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
