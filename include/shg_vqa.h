@@ -259,6 +259,12 @@ int shg_attention_bwd(const void* q, const void* k, const void* v, const void* o
 int shg_gemm(const void* a, const void* b, void* c, const float* bias, int dtype_ab, int dtype_c, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
              int accumulate, void* stream);
+/* C [M, N] (+)= sum over n_seg segments of A_s [M, seg_k] . B_s [seg_k, N] in ONE launch: A_s = a + s * a_seg_stride (elements; rows
+ * of lda, the contraction index contiguous), B_s = b + s * b_seg_stride (rows = contraction index, ldb).  The gradient of the
+ * decoders w.r.t. their memory (transformer.py:212-233 in reverse: every layer's cross-attention adds dK/dV . W_kv) as one K = layers x
+ * 2 H contraction instead of one accumulating GEMM per layer (one rounding of the sum to the output type instead of one per layer). */
+int shg_gemm_kseg(const void* a, const void* b, void* c, int dtype, int64_t M, int64_t N, int64_t seg_k, int n_seg, int64_t lda,
+                  int64_t ldb, int64_t ldc, int64_t a_seg_stride, int64_t b_seg_stride, int accumulate, void* stream);
 /* Weight gradients of n nn.Linear layers in as few launches as possible:  gw[n_out, n_in] += dy[rows, n_out]^T . x[rows, n_in]
  * (fp32 gradient, row stride n_in; dy / x row strides ldy / ldx).  Runs of bf16 problems with rows % 64 == 0 go out as ONE
  * grid of 256 x 256 tiles over all of them (a decoder layer's eight weight gradients are 9-24 tiles each: alone none fills a

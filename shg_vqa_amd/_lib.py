@@ -48,6 +48,7 @@ _SIGNATURES = {
     "shg_attention_bwd": ([P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, L,
                            I, P, F, F, P, U, P, P, P, P, P], c_int),
     "shg_gemm": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P], c_int),
+    "shg_gemm_kseg": ([P, P, P, I, L, L, L, I, L, L, L, L, L, I, P], c_int),
     "shg_gemm_dact": ([P, P, P, P, P, I, L, L, L, L, L, L, I, F, P, U, P], c_int),
     "shg_gemm_act": ([P, P, P, P, I, I, L, L, L, L, L, L, I, I, I, P, F, P, U, P], c_int),
     "shg_conv3d_k533_workspace_bytes": ([I, I, I, I], c_int64),

@@ -694,6 +694,25 @@ extern "C" int shg_decoder_bwd(const shg_decoder_layer_t* layers, int n_layers, 
     void* st = R->stream;
     const void* dy = d_out;
     bool pos_init = true, mem_init = true;
+    // d_memory = sum over the layers of dK/dV_l . W_kv_l.  The layers' dK/dV live in their own scratch blocks, the weights in the
+    // parameter arena - both at a constant stride from layer to layer - so the sum is ONE GEMM over K = layers x 2 H after the loop
+    // (shg_gemm_kseg) instead of one accumulating 12 576 x 768 x 1 536 GEMM per layer in the middle of the chain.
+    const int64_t es_ = esize(dt), rk_ = (int64_t)B * S;
+    bool kseg = d_memory && n_layers >= 2 && dt == SHG_BF16 && tuning(TUNE_DECODER_KSEG);
+    int64_t a_stride = 0, b_stride = 0;
+    if (kseg) {
+        const char* a0 = (const char*)attn_scratch(w.layer[0].w_cross, SHG_ATTN_DEC_CROSS, dt, B, Q, S, heads).dkv;
+        const char* a1 = (const char*)attn_scratch(w.layer[1].w_cross, SHG_ATTN_DEC_CROSS, dt, B, Q, S, heads).dkv;
+        const char* b0 = (const char*)layers[0].cross_attn.b.w;
+        const char* b1 = (const char*)layers[1].cross_attn.b.w;
+        a_stride = a1 - a0;
+        b_stride = b1 - b0;
+        for (int i = 0; kseg && i < n_layers; ++i) {
+            const char* ai = (const char*)attn_scratch(w.layer[i].w_cross, SHG_ATTN_DEC_CROSS, dt, B, Q, S, heads).dkv;
+            kseg = ai == a0 + i * a_stride && (const char*)layers[i].cross_attn.b.w == b0 + i * b_stride && layers[i].cross_attn.b.w != nullptr;
+        }
+        kseg = kseg && a_stride % 16 == 0 && b_stride % 16 == 0;
+    }
     for (int i = n_layers - 1; i >= 0; --i) {
         const shg_decoder_layer_t& L = layers[i];
         const DecLayerBufs& b = d.layer[i];
@@ -704,8 +723,8 @@ extern "C" int shg_decoder_bwd(const shg_decoder_layer_t* layers, int n_layers, 
         const bool need_x = i > 0 || d_tgt != nullptr;
         void* d0 = need_x ? (i == 0 ? d_tgt : s.d0) : nullptr;
         CK(ffn_bwd(&L.ffn, R, rq, (int)H, F, b.y2, b.s_ffn, dy, s.d2, s.w_ffn, sid + 6 * i + 4));
-        CK(attn_bwd(&L.cross_attn, R, B, Q, S, b.y1, b.y1p, memory, b.s_cross, s.d2, s.d1, s.dxp_b, d_memory, mem_init ? 0 : 1, s.w_cross,
-                    sid + 6 * i + 2));
+        CK(attn_bwd(&L.cross_attn, R, B, Q, S, b.y1, b.y1p, memory, b.s_cross, s.d2, s.d1, s.dxp_b, kseg ? nullptr : d_memory, mem_init ? 0 : 1,
+                    s.w_cross, sid + 6 * i + 2));
         mem_init = false;
         // y1p = y1 + pos: its gradient goes to y1 and to pos
         CK(shg_add2_accumulate(s.d1, d_query_pos, s.dxp_b, pos_init ? 1 : 0, dt, n, st));
@@ -715,6 +734,10 @@ extern "C" int shg_decoder_bwd(const shg_decoder_layer_t* layers, int n_layers, 
                     sid + 6 * i));
         if (want_xp) CK(shg_add2_accumulate(d0, d_query_pos, s.dxp_a, 0, dt, n, st));     // xp = x + pos likewise
         dy = s.d0;
+    }
+    if (kseg) {
+        const void* a0 = attn_scratch(w.layer[0].w_cross, SHG_ATTN_DEC_CROSS, dt, B, Q, S, heads).dkv;
+        CK(shg_gemm_kseg(a0, layers[0].cross_attn.b.w, d_memory, dt, rk_, H, 2 * H, n_layers, 2 * H, H, H, a_stride / es_, b_stride / es_, 0, st));
     }
     return 0;
 }

@@ -119,6 +119,20 @@ template <typename T, bool KMAJ> struct PlainSrc {
     }
 };
 
+// An operand whose contraction index runs over n_seg separate matrices of seg_tiles K-tiles each, seg_stride elements apart
+// (shg_gemm_kseg: C = sum_s A_s . B_s as ONE launch - the decoders' gradient w.r.t. their memory, five `C +=` GEMMs before)
+template <typename T, bool KMAJ> struct SegSrc : PlainSrc<T, KMAJ> {
+    int seg_tiles;
+    uint32_t seg_magic;       // (1 << 20) / seg_tiles + 1: K-tile / seg_tiles for K-tile < 4 095
+    int64_t seg_stride;
+    __device__ __forceinline__ const char* k_base(int, int64_t k0) const {
+        const uint32_t kt = (uint32_t)(k0 >> 6), q = (kt * seg_magic) >> 20;
+        const int64_t k = k0 - (int64_t)q * seg_tiles * 64;
+        const T* base = this->p + (int64_t)q * seg_stride;
+        return reinterpret_cast<const char*>(KMAJ ? base + k : base + k * this->ld);
+    }
+};
+
 struct ConvGeom {
     int Cin, Hp, Wp;          // padded input plane
     uint32_t inv_cin;         // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, inv_cin) for k < 2^32 / Cin
@@ -2238,6 +2252,34 @@ extern "C" int shg_gemm(const void* a, const void* b, void* c, const float* bias
         SHG_REPEAT(2048, shg_gemm(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, stream));
     return gemm_entry(a, b, c, bias, dtype_ab, dtype_c, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, accumulate, SHG_ACT_NONE,
                       nullptr, stream);
+}
+
+extern "C" int shg_gemm_kseg(const void* a, const void* b, void* c, int dtype, int64_t M, int64_t N, int64_t seg_k, int n_seg,
+                             int64_t lda, int64_t ldb, int64_t ldc, int64_t a_seg_stride, int64_t b_seg_stride, int accumulate,
+                             void* stream) {
+    if (!a || !b || !c) return fail_arg("gemm_kseg: null pointer");
+    if (M <= 0 || N <= 0 || seg_k <= 0 || n_seg < 1 || n_seg > 64) return fail_arg("gemm_kseg: bad sizes");
+    if (dtype != SHG_F32 && dtype != SHG_BF16) return fail_arg("gemm_kseg: bad dtype");
+    const int64_t es = dtype == SHG_BF16 ? 2 : 4, epc = 16 / es;
+    if (a_seg_stride % epc || b_seg_stride % epc) return fail_arg("gemm_kseg: segment strides must keep 16-byte alignment");
+    const int64_t K = seg_k * n_seg, gm = (M + 255) / 256, gn = (N + 255) / 256;
+    if (dtype == SHG_BF16 && seg_k % BK == 0 && K / BK < 4000 && N % 8 == 0 && ldc % 8 == 0 && al16(a) && al16(b) && al16(c) && lda % 8 == 0 &&
+        ldb % 8 == 0 && lda >= seg_k && ldb >= N && ldc >= N && tuning(TUNE_GEMM8) && gm * gn >= tuning(TUNE_GEMM8_MIN_TILES) &&
+        M * lda * es < ((int64_t)1 << 32) && (int64_t)64 * ldb * es < ((int64_t)1 << 32)) {
+        SHG_REPEAT(2048, shg_gemm_kseg(a, b, c, dtype, M, N, seg_k, n_seg, lda, ldb, ldc, a_seg_stride, b_seg_stride, 1, stream));
+        const int st_tiles = (int)(seg_k / BK);
+        const uint32_t magic = (1u << 20) / (uint32_t)st_tiles + 1u;
+        SegSrc<bf16_t, true> sa{{(const bf16_t*)a, lda, 0, M, K}, st_tiles, magic, a_seg_stride};
+        SegSrc<bf16_t, false> sb{{(const bf16_t*)b, ldb, 0, N, K}, st_tiles, magic, b_seg_stride};
+        Epilogue<bf16_t> ep{(bf16_t*)c, ldc, nullptr, nullptr, SHG_ACT_NONE, accumulate ? 1 : 0, 1, nullptr, 0, nullptr, nullptr, 0, 1.f, nullptr, 0,
+                            tuning(TUNE_EPILOGUE_SIDE) ? 0 : 1};
+        return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, (hipStream_t)stream, "gemm_kseg");
+    }
+    for (int s = 0; s < n_seg; ++s)                  // elsewhere: the segments one after the other
+        if (int e = shg_gemm((const char*)a + s * a_seg_stride * es, (const char*)b + s * b_seg_stride * es, c, nullptr, dtype, dtype, M, N, seg_k, lda,
+                             ldb, ldc, 1, 0, (accumulate || s > 0) ? 1 : 0, stream))
+            return e;
+    return 0;
 }
 
 static int drop_args_ok(float p_drop, const uint64_t* seed_state, int64_t N) {

@@ -609,6 +609,19 @@ def grad_norm(flat_grad, partial=None):
     return out
 
 
+def gemm_kseg(a_segs, b_segs, out, accumulate=False):
+    """out [M, N] (+)= sum_s a_segs[s] [M, k] @ b_segs[s] [k, N] as one launch (shg_gemm_kseg).  a_segs / b_segs: 3-D tensors [n_seg, M, k] /
+    [n_seg, k, N] (any stride between the segments, rows contiguous)."""
+    _dev(a_segs, b_segs, out)
+    n, M, k = a_segs.shape
+    N = b_segs.shape[2]
+    _need(b_segs.shape[0] == n and b_segs.shape[1] == k and tuple(out.shape) == (M, N), "shapes do not match")
+    _need(a_segs.stride(2) == 1 and b_segs.stride(2) == 1 and out.is_contiguous() and a_segs.dtype == b_segs.dtype == out.dtype, "row-contiguous operands of one dtype")
+    _lib.call("shg_gemm_kseg", a_segs.data_ptr(), b_segs.data_ptr(), out.data_ptr(), _dt(out), M, N, k, n, a_segs.stride(1), b_segs.stride(1), N,
+              a_segs.stride(0), b_segs.stride(0), 1 if accumulate else 0, _stream())
+    return out
+
+
 def grad_norm_ranges(flat_grad, ranges, extra=None):
     """L2 norm over the element ranges [(lo, hi), ..] of a flat fp32 arena (lo, hi multiples of 4) plus sqrt-under-the-root of
     extra[0] (float64 [1], sums other kernels accumulated; reset to 0 by the call) -> fp32 [1]."""

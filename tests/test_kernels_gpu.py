@@ -1161,6 +1161,26 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
     assert err <= 2e-4 * ref.abs().max().item() + 1e-3          # fp32 accumulation order only
 
 
+@pytest.mark.parametrize("M,N,k,n_seg", [(12576, 768, 1536, 5), (300, 96, 128, 3)])
+def test_gemm_over_k_segments(K, M, N, k, n_seg):
+    """shg_gemm_kseg: sum over segments of A_s . B_s in one launch (the decoders' gradient w.r.t. their memory: 8-phase kernel at
+    12 576 x 768, five segments of 1 536) and its segment-by-segment fallback, against fp32 matmuls of the same bf16 operands; padded
+    strides between the segments as in the executor's scratch / the parameter arena."""
+    gen = torch.Generator().manual_seed(M + k)
+    a = torch.randn(n_seg, M + 3, k, generator=gen).to(DEV).bfloat16()[:, :M]                  # (segment stride (M + 3) k)
+    b = (torch.randn(n_seg, k + 16, N, generator=gen) / math.sqrt(k * n_seg)).to(DEV).bfloat16()[:, :k]
+    ref = sum(a[s].float() @ b[s].float() for s in range(n_seg))
+    out = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+    K.gemm_kseg(a, b, out)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2 ** -7 * ref.abs().max().item() + 1e-3, err
+    base = torch.randn(M, N, generator=gen).to(DEV).bfloat16()
+    out2 = base.clone()
+    K.gemm_kseg(a, b, out2, accumulate=True)
+    err2 = (out2.float() - (ref + base.float())).abs().max().item()
+    assert err2 <= 2 ** -6 * (ref.abs().max().item() + base.abs().max().item()) + 1e-3, err2
+
+
 def test_bias_act_bwd_with_a_row_table(K):
     """shg_bias_act_bwd_rows: result row r reads x / writes dx at row x_rows[r]; dy (a grouped view), the scattered second output and
     the bias-gradient partial sums stay indexed by r."""
