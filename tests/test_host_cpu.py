@@ -297,6 +297,35 @@ def test_weighted_streamk_plan_covers_tiles_of_different_length():
         assert len(busy) >= 250 and max(busy) <= slack * sigma / 100 * sum(nk) / 256, (n_tiles, min(busy), max(busy), sum(nk) / 256)
 
 
+def test_single_writer_gradient_bookkeeping():
+    """Engine.claim_overwrite / settle_stale_grads (host logic of the single-writer gradients): a gradient the optimiser left
+    unzeroed is overwritten again, or zeroed before anything accumulates into it or reads it; a second writer in one step poisons the
+    fused norm; nothing is claimed on a device without the kernels."""
+    import types
+    import torch
+    from shg_vqa_amd.engine import Engine
+    e = Engine(compute_dtype=torch.float32, device="cpu")
+    e.grad_arena = torch.ones(64)
+    p = types.SimpleNamespace(_shg_off=8, _shg_numel=16, _shg_grad=e.grad_arena[8:24])
+    assert e.claim_overwrite(p) is False and not e.overwritten          # (cpu: the accumulate path, always)
+    # what the cuda path records, replayed by hand: set in step 1, left unzeroed by the optimiser ...
+    e.overwritten = {8: 16}
+    e.unzeroed, e.overwritten = dict(e.overwritten), {}
+    # ... step 2 does not touch it: stale values must not survive to the norm / the update
+    e.settle_stale_grads()
+    assert not e.unzeroed and float(e.grad_arena[8:24].abs().sum()) == 0.0 and float(e.grad_arena[:8].sum()) == 8.0
+    # ... or step 2 accumulates into it (fallback path): zeroed first
+    e.grad_arena.fill_(1.0)
+    e.unzeroed = {8: 16}
+    assert e.claim_overwrite(p) is False and not e.unzeroed and float(p._shg_grad.abs().sum()) == 0.0
+    # a second writer of an already overwritten gradient in the same step: the fused sum no longer describes it
+    e.overwritten = {8: 16}
+    assert e.claim_overwrite(p) is False and e.overwrite_poisoned
+    e.grad_dirty = True
+    e.zero_grad()
+    assert not e.overwritten and not e.unzeroed and not e.overwrite_poisoned and float(e.grad_arena.abs().sum()) == 0.0
+
+
 def test_bench_constants_follow_the_survey_flop_table():
     """bench.py prices its fractions with SURVEY section 8(d): 428.21 / 178.79 / 45.50 GFLOP per QA pair (training, forward, the
     attention stack's forward) and conv1 = 83.236 GFLOP per QA pair = 2 x (12 x 49) x 768 x (45 x 2048) flop."""
