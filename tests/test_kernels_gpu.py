@@ -1147,6 +1147,11 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
             K.conv3d_k533_wgrad_sumsq(xi.bfloat16(), dy_pm, dw, ss, order=1)
             assert torch.equal(dw.view(Cout, -1), ref), skip
             assert abs(ss.item() - want) <= 1e-6 * want, (skip, ss.item(), want)
+            # the data-parallel step's form: accumulating output-channel slices (2/3 + 1/3) in the same row order
+            dw.zero_()
+            K.conv3d_k533_wgrad(xi.bfloat16(), dy_pm, dw, accumulate=True, c0=0, cn=512, order=1)
+            K.conv3d_k533_wgrad(xi.bfloat16(), dy_pm, dw, accumulate=True, c0=512, cn=256, order=1)
+            assert torch.equal(dw.view(Cout, -1), ref), skip
         finally:
             _lib.set_tuning("conv_k_order", 62)
     del ref, xi, dyi, dy_pm
