@@ -343,7 +343,10 @@ int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dt
  *     order 0 (each ((M * 4 + 255) / 256) * 256 bytes): std2row[m] = position-major row of standard row m, row2std = its inverse.
  *   shg_conv3d_k533_fwd takes either workspace (its dense outputs y_pre / y then have that row order; pad_out output is a layout,
  *     not an order).  shg_conv3d_k533_dgrad_rows: row m of dx is written at dx_rows[m] (the NEXT layer's std2row: its input
- *     gradient arrives in the order its weight gradient contracts over); NULL = shg_conv3d_k533_dgrad.
+ *     gradient arrives in the order its weight gradient contracts over); row_order 2 = FRAME-MAJOR tables (row = ((to B + b) H + h)
+ *     W + w, workspace_bytes_ex / prepare_ex with 2): dy is padded by four frames, so 20 of the 60 (output frame, kt) pairs read
+ *     padding - a tile keeps the temporal taps that read data for any of its frames (needs streamk_workspace: the weighted plan
+ *     balances the tiles); NULL tables / row_order 0 / NULL workspace = shg_conv3d_k533_dgrad.
  *   shg_conv3d_k533_wgrad_ex: the general weight gradient - slice [c0, c0 + cn), accumulate or overwrite, optional fused sum of
  *     squares (only with accumulate = 0), row order of x's table / dy's rows. */
 /* shg_conv3d_k533_fwd with row tables: the pre-activation row m is written at row pre_rows[m], the dense output (pad_out = 0) row m
@@ -356,7 +359,8 @@ int shg_conv3d_k533_fwd_rows(const void* x, const void* w, const float* bias, vo
 int64_t shg_conv3d_k533_workspace_bytes_ex(int B, int T, int H, int W, int row_order);
 int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, int W, int row_order, void* stream);
 int shg_conv3d_k533_dgrad_rows(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
-                               int Cin, int Cout, const int32_t* dx_rows, const void* workspace, void* stream);
+                               int Cin, int Cout, const int32_t* dx_rows, int row_order, const void* workspace,
+                               void* streamk_workspace, void* stream);
 int shg_conv3d_k533_wgrad_ex(const void* x, const void* dy, float* dw, int dtype, int B, int T, int H, int W, int Cin,
                              int Cout, int c0, int cn, int accumulate, double* sumsq, int row_order, const void* workspace,
                              void* stream);

@@ -61,7 +61,7 @@ _SIGNATURES = {
     "shg_conv3d_k533_wgrad_slice": ([P, P, P, I, I, I, I, I, I, I, I, I, I, P, P], c_int),
     "shg_conv3d_k533_wgrad_sumsq": ([P, P, P, I, I, I, I, I, I, I, I, I, P, P, P], c_int),
     "shg_conv3d_k533_wgrad_ex": ([P, P, P, I, I, I, I, I, I, I, I, I, I, P, I, P, P], c_int),
-    "shg_conv3d_k533_dgrad_rows": ([P, P, P, I, I, I, I, I, I, I, P, P, P], c_int),
+    "shg_conv3d_k533_dgrad_rows": ([P, P, P, I, I, I, I, I, I, I, P, I, P, P, P], c_int),
     "shg_conv3d_k533_workspace_bytes_ex": ([I, I, I, I, I], c_int64),
     "shg_conv3d_k533_prepare_ex": ([P, I, I, I, I, I, P], c_int),
     "shg_conv3d_k533_dgrad": ([P, P, P, I, I, I, I, I, I, I, P, P], c_int),

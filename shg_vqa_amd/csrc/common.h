@@ -63,7 +63,9 @@ enum Tune {
                                // rows (shg_conv3d_k533_wgrad_ex, row_order 1): skip the K-tiles of positions where the tile's tap reads
                                // the zero border.  Bit 4: with that, the taps of a channel block longest first.  Bit 5, forward with position-major
                                // rows (shg_conv3d_k533_fwd_rows, row_order 1): a tile leaves out the taps that read only the zero border
-                               // for all its rows; the stream-K launch then uses the weighted plan (62) - "conv_k_order"
+                               // for all its rows; the stream-K launch then uses the weighted plan.  Bit 6, input gradient with frame-major rows
+                               // (shg_conv3d_k533_dgrad_rows, row_order 2): a tile leaves out the temporal taps that read only padding
+                               // frames, stream-K with the weighted plan (126) - "conv_k_order"
     TUNE_DECODER_KSEG,         // decoder backward: the gradient w.r.t. the memory as ONE GEMM over all layers' dK/dV (1) - "decoder_kseg"
     TUNE_WGRAD_GROUP_CAP,      // grouped weight gradients: workgroups per launch (256 = one round of the CUs) - "wgrad_group_cap"
     TUNE_WGRAD_GROUP_SPLIT,    // ... and parts of every problem's contraction (1) - "wgrad_group_split"

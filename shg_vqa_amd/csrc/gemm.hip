@@ -138,13 +138,14 @@ struct ConvGeom {
     uint32_t inv_cin;         // floor(2^32 / Cin) + 1: k / Cin == umulhi(k, inv_cin) for k < 2^32 / Cin
     int kperm;                // 8-phase kernel: visit the K-tiles channel-block-major (all 45 taps of 64 channels, then the next 64)
     int rpp;                  // forward in position-major row order: rows per spatial position (B To), 0 = every tap for every tile
-};
+    int rpt, tv_lo, tv_hi;    // input gradient in frame-major row order: rows per output frame (B H W; 0 = off) and the frames of the
+};                            // padded gradient that hold data, [tv_lo, tv_hi): tap kt of output frame t reads frame t + kt
 static int conv_k_order(int Cin) {                     // 0: storage order; n: blocks of 64 * 2^(n-1) channels, n <= 3
     const int n = (int)tuning(TUNE_CONV_K_ORDER) & 3;
     return (n >= 1 && n <= 3 && Cin % (64 << (n - 1)) == 0) ? n : 0;
 }
 static ConvGeom conv_geom(int Cin, int Hp, int Wp) {
-    return ConvGeom{Cin, Hp, Wp, (uint32_t)(0x100000000ull / (uint32_t)Cin) + 1u, conv_k_order(Cin), 0};
+    return ConvGeom{Cin, Hp, Wp, (uint32_t)(0x100000000ull / (uint32_t)Cin) + 1u, conv_k_order(Cin), 0, 0, 0, 0};
 }
 // tap < 45 -> (kt, kh, kw) by multiply-shift (exact on that range): the wave-uniform address math of the
 // direct-to-LDS loads sits in the instruction stream of the load phase, where an integer division costs ~30 instructions
@@ -173,6 +174,28 @@ __host__ __device__ __forceinline__ uint32_t conv_tile_mask9(int64_t m0, int64_t
     return m;
 }
 
+// temporal taps kt (0 .. 4) that read a data frame for ANY of the output frames of rows [m0, m0 + 255] of a frame-major problem:
+// a contiguous range [lo, hi] (the union of the frames' ranges [tv_lo - t, tv_hi - 1 - t])
+__host__ __device__ __forceinline__ void conv_tile_kt_range(int64_t m0, int64_t M, int rpt, int tv_lo, int tv_hi, int& lo, int& hi) {
+    const int64_t m1 = (m0 + 255 < M ? m0 + 255 : M - 1);
+    const int t0 = (int)(m0 / rpt), t1 = (int)(m1 / rpt);
+    lo = tv_lo - t1;
+    hi = tv_hi - 1 - t0;
+    if (lo < 0) lo = 0;
+    if (hi > 4) hi = 4;
+    if (hi < lo) hi = lo;                            // (cannot happen for a frame inside the problem; keeps the list non-empty)
+}
+// K-tiles a 256-row tile keeps (host: the weighted stream-K plan's table; device: ConvRowSrc::set_tile computes the same)
+static int conv_tile_nk(const ConvGeom& g, int64_t m0, int64_t M) {
+    if (g.rpt) {
+        int lo, hi;
+        conv_tile_kt_range(m0, M, g.rpt, g.tv_lo, g.tv_hi, lo, hi);
+        return 9 * (hi - lo + 1) * (g.Cin / 64);
+    }
+    if (g.rpp) return 5 * __builtin_popcount(conv_tile_mask9(m0, M, g.rpp, g.Hp - 2, g.Wp - 2)) * (g.Cin / 64);
+    return 45 * (g.Cin / 64);
+}
+
 // A operand of the conv forward: rows = output positions (gathered), K = (tap, channel), K contiguous.
 template <typename T, int NTHR, bool SKIP_ = false> struct ConvRowSrc {
     static constexpr bool KMAJOR = true;
@@ -188,7 +211,16 @@ template <typename T, int NTHR, bool SKIP_ = false> struct ConvRowSrc {
     // only the zero border for every one of them.  set_tile: the tile's list of taps - n9 of the 9 (kh, kw), their numbers as
     // nibbles - and the K-tiles it leaves: 5 n9 taps x Cin / 64.  g.rpp == 0 (any row order): all 45.
     __device__ __forceinline__ int set_tile(int64_t m0) {
-        if (!SKIP || !g.rpp) return 45 * (g.Cin >> 6);
+        if (!SKIP || (!g.rpp && !g.rpt)) return 45 * (g.Cin >> 6);
+        if (g.rpt) {                                 // frame-major rows (input gradient): all nine (kh, kw), the temporal taps that read data
+            int lo, hi;
+            conv_tile_kt_range(m0, M, g.rpt, g.tv_lo, g.tv_hi, lo, hi);
+            kt_lo = (uint32_t)lo;
+            nib = 0x876543210ull; n9 = 9; ntaps = 9u * (uint32_t)(hi - lo + 1);
+            ntaps_magic = (1u << 20) / ntaps + 1;
+            n9_magic = (1u << 20) / 9 + 1;
+            return (int)(ntaps * (uint32_t)(g.Cin >> 6));
+        }
         const uint32_t mask = conv_tile_mask9(m0, M, g.rpp, g.Hp - 2, g.Wp - 2);
         uint64_t nb = 0;
         uint32_t c = 0;
@@ -212,7 +244,7 @@ template <typename T, int NTHR, bool SKIP_ = false> struct ConvRowSrc {
         // q / ntaps, then the tap's place in the tile's list -> its number (x / d == (x * ((1 << 20) / d + 1)) >> 20 for x < 4 095)
         const uint32_t blk = (q * ntaps_magic) >> 20, j = q - blk * ntaps;
         const uint32_t k3 = (j * n9_magic) >> 20, s9 = j - k3 * n9;
-        const uint32_t tap = 9u * k3 + ((uint32_t)(nib >> (4u * s9)) & 15u);
+        const uint32_t tap = 9u * (kt_lo + k3) + ((uint32_t)(nib >> (4u * s9)) & 15u);
         const uint32_t kp = tap * (uint32_t)g.Cin + (((blk << sh) + sub) << 6);
         return (int64_t)(g.kperm ? kp : k << 6);
     }
@@ -224,6 +256,7 @@ template <typename T, int NTHR, bool SKIP_ = false> struct ConvRowSrc {
     bool okr[Stage<T>::NCH];
     uint32_t n9 = 9, ntaps = 45, ntaps_magic = (1u << 20) / 45 + 1, n9_magic = (1u << 20) / 9 + 1;      // set_tile()
     uint64_t nib = 0x876543210ull;
+    uint32_t kt_lo = 0;
     __device__ __forceinline__ void prepare(int tid) {
 #pragma unroll
         for (int i = 0; i < Stage<T>::NCH; ++i) {
@@ -1872,14 +1905,13 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
                 sk.sigma = (int)sg;
                 G8SkArgs<TC, SrcA, SrcB> args{{sa, sb, ep, M, N, K, tile_order(gm, gn), sk, 0}, {}};
                 if constexpr (SrcA::SKIP) {
-                    if (sa.g.rpp) {                  // position-major rows: tiles of different length -> the weighted plan
+                    if (sa.g.rpp || sa.g.rpt) {      // position- / frame-major rows: tiles of different length -> the weighted plan
                         uint16_t nkt[256];
                         const int go = args.core.grid_m;
                         const int64_t gm_t = go < 0 ? -go : go, gn_t = tiles / gm_t;
                         for (int64_t t = 0; t < tiles; ++t) {
                             const int64_t bm = go < 0 ? t % gm_t : t / gn_t;
-                            const uint32_t m9 = conv_tile_mask9(bm * 256, M, sa.g.rpp, sa.g.Hp - 2, sa.g.Wp - 2);
-                            nkt[t] = (uint16_t)(5 * __builtin_popcount(m9) * (sa.g.Cin / 64));
+                            nkt[t] = (uint16_t)conv_tile_nk(sa.g, bm * 256, M);
                         }
                         // (the tables depend on the shape only: built once per shape and thread, ~2 ms of host time)
                         static thread_local std::vector<uint16_t> key;
@@ -1891,7 +1923,7 @@ static int launch8(SrcA sa, SrcB sb, Epilogue<TC> ep, int64_t M, int64_t N, int6
                             cached_ok = streamk_w_build(cached, (int)tiles, nkt, (int)sg) ? 1 : 0;
                         }
                         if (cached_ok) { args.wt = cached; args.core.weighted = 1; }
-                        else args.core.sa.g.rpp = 0; // (no weighted plan for these lengths: every tap for every tile, the uniform plan)
+                        else { args.core.sa.g.rpp = 0; args.core.sa.g.rpt = 0; }   // (no weighted plan for these lengths: every tap, the uniform plan)
                     }
                 }
                 g_streamk_launches.fetch_add(1, std::memory_order_relaxed);
@@ -2021,14 +2053,15 @@ __global__ void conv_pos_kernel(int32_t* pos_in, int32_t* pos_out, int B, int Ti
 // Row order 1 (position-major): row r = ((h W + w) B + b) To + to.  Same tables for that order, plus std2row[m] = r for the
 // standard row m = ((b To + to) H + h) W + w (a producer that computes rows in standard order - the next convolution's input
 // gradient - writes them where this order expects them).
+// Row order 2 (frame-major): row r = ((to B + b) H + h) W + w - every output frame's rows together.
 __global__ void conv_pos_grouped_kernel(int32_t* pos_in, int32_t* pos_out, int32_t* std2row, int32_t* row2std, int B, int Tin, int To, int H,
-                                        int W) {
+                                        int W, int order) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t M = (int64_t)B * To * H * W;
     if (m >= M) return;
     const int w = (int)(m % W), h = (int)((m / W) % H), to = (int)((m / ((int64_t)W * H)) % To), b = (int)(m / ((int64_t)W * H * To));
     const int Hp = H + 2, Wp = W + 2;
-    const int64_t r = (((int64_t)h * W + w) * B + b) * To + to;
+    const int64_t r = order == 2 ? (((int64_t)to * B + b) * H + h) * W + w : (((int64_t)h * W + w) * B + b) * To + to;
     pos_in[r] = (int32_t)((((int64_t)b * Tin + to) * Hp + h) * Wp + w);
     pos_out[r] = (int32_t)((((int64_t)b * To + to) * Hp + h + 1) * Wp + w + 1);
     std2row[m] = (int32_t)r;
@@ -2355,20 +2388,20 @@ extern "C" int shg_conv3d_k533_prepare(void* workspace, int B, int T, int H, int
 
 extern "C" int64_t shg_conv3d_k533_workspace_bytes_ex(int B, int T, int H, int W, int row_order) {
     const int64_t two = shg_conv3d_k533_workspace_bytes(B, T, H, W);
-    if (two < 0 || row_order < 0 || row_order > 1) return -1;
+    if (two < 0 || row_order < 0 || row_order > 2) return -1;
     return row_order ? two * 2 : two;
 }
 
 extern "C" int shg_conv3d_k533_prepare_ex(void* workspace, int B, int T, int H, int W, int row_order, void* stream) {
     if (row_order == 0) return shg_conv3d_k533_prepare(workspace, B, T, H, W, stream);
-    if (!workspace || B < 1 || T < 5 || H < 1 || W < 1 || row_order != 1) return fail_arg("conv3d_prepare_ex: bad argument");
+    if (!workspace || B < 1 || T < 5 || H < 1 || W < 1 || row_order < 1 || row_order > 2) return fail_arg("conv3d_prepare_ex: bad argument");
     const int64_t M = (int64_t)B * (T - 4) * H * W, seg = shg_conv3d_k533_workspace_bytes(B, T, H, W) / 2;
     int32_t* pos_in = (int32_t*)workspace;
     int32_t* pos_out = (int32_t*)((char*)workspace + seg);
     int32_t* std2row = (int32_t*)((char*)workspace + 2 * seg);
     int32_t* row2std = (int32_t*)((char*)workspace + 3 * seg);
     hipLaunchKernelGGL(conv_pos_grouped_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos_in, pos_out, std2row,
-                       row2std, B, T, T - 4, H, W);
+                       row2std, B, T, T - 4, H, W, row_order);
     return check_launch("conv3d_prepare_ex");
 }
 
@@ -2601,12 +2634,15 @@ extern "C" int shg_conv3d_k533_wgrad(const void* x, const void* dy, float* dw, i
 
 extern "C" int shg_conv3d_k533_dgrad(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
                                      int Cin, int Cout, const void* workspace, void* stream) {
-    return shg_conv3d_k533_dgrad_rows(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, nullptr, workspace, stream);
+    return shg_conv3d_k533_dgrad_rows(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, nullptr, 0, workspace, nullptr, stream);
 }
 
 extern "C" int shg_conv3d_k533_dgrad_rows(const void* dy_padded, const void* w, void* dx, int dtype, int B, int Tp, int H, int W,
-                                          int Cin, int Cout, const int32_t* dx_rows, const void* workspace, void* stream) {
-    SHG_REPEAT(512, shg_conv3d_k533_dgrad_rows(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, dx_rows, workspace, stream));
+                                          int Cin, int Cout, const int32_t* dx_rows, int row_order, const void* workspace, void* streamk_ws,
+                                          void* stream) {
+    SHG_REPEAT(512, shg_conv3d_k533_dgrad_rows(dy_padded, w, dx, dtype, B, Tp, H, W, Cin, Cout, dx_rows, row_order, workspace, streamk_ws, stream));
+    if (row_order != 0 && row_order != 2) return fail_arg("conv3d_dgrad_rows: row_order must be 0 (standard) or 2 (frame-major)");
+    if (streamk_ws && !al16(streamk_ws)) return fail_arg("conv3d_dgrad_rows: streamk workspace must be 16-byte aligned");
     // dx[b,t,h,w,ci] = sum_{tap',co} dYp[b, t+kt', h+kh', w+kw', co] * W[co][44-tap'][ci]; dYp = dy padded by
     // 4 in T and 1 in H/W, so this is the forward gather over dYp with the weight read "contraction strided".
     if (!dy_padded || !w || !dx) return fail_arg("conv3d_dgrad: null pointer");
@@ -2626,6 +2662,16 @@ extern "C" int shg_conv3d_k533_dgrad_rows(const void* dy_padded, const void* w, 
     ConvWeightColSrc<bf16_t> sb{(const bf16_t*)w, 0, N, K, Cin, Cout, (uint32_t)(0x100000000ull / (uint32_t)Cout) + 1u};
     Epilogue<bf16_t> ep{(bf16_t*)dx, Cin, nullptr, dx_rows, SHG_ACT_NONE, 0, 1, nullptr, 0};
     if (Cout % 64 == 0 && use_gemm8(M, N, K, (int64_t)B * Tp * (H + 2) * (W + 2) * Cout * 2, (int64_t)64 * 45 * Cin * 2)) {
+        // frame-major rows (the caller's tables are of row order 2): 40 of the 60 (output frame, kt) pairs of a dy padded by four frames
+        // read data; a tile keeps the temporal taps that do for any of its frames, the stream-K launch balances the lengths with the
+        // weighted plan ("conv_k_order" bit 6)
+        if (row_order == 2 && g.kperm && streamk_ws && (tuning(TUNE_CONV_K_ORDER) & 64) && (int64_t)45 * (Cout / 64) < 4000) {
+            g.rpt = B * H * W;
+            g.tv_lo = 4;
+            g.tv_hi = Tp - 4;
+            ConvRowSrc<bf16_t, 512, true> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
+            return launch8<bf16_t, decltype(sa), decltype(sb), 1>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad", 1, streamk_ws);
+        }
         ConvRowSrc<bf16_t, 512> sa{(const bf16_t*)dy_padded, pos_in, 0, M, g};
         return launch8<bf16_t, decltype(sa), decltype(sb)>(sa, sb, ep, M, N, K, st, "conv3d_k533_dgrad");
     }

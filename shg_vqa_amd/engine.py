@@ -102,6 +102,9 @@ class Engine:
         self.conv1_row_order = int(os.environ.get("SHG_CONV1_ROW_ORDER", "1"))
         # the conv FORWARDS in position-major rows too: tiles leave out the taps that read only the zero border, the stream-K launch
         # balances their different lengths with its weighted plan ("conv_k_order" bit 5)
+        # conv2's input gradient in frame-major rows: tiles leave out the temporal taps that read the four padding frames
+        # ("conv_k_order" bit 6, weighted stream-K plan)
+        self.conv_dgrad_tm = int(os.environ.get("SHG_CONV_DGRAD_TM", "0"))
         self.conv_fwd_pm = int(os.environ.get("SHG_CONV_FWD_PM", "2"))     # bit 0: conv1 (off: -0.13 ms per step, but 5.8 instead of 2.6 GB of L2 misses per launch - its tiles stop walking K together), bit 1: conv2
         self.norm_extra = None
         self.overwritten, self.unzeroed = {}, {}

@@ -457,16 +457,16 @@ def conv_workspace(B, T, H, W, device, order=0):
     return ws
 
 
-def conv_row_table(B, T, H, W, device):
-    """int32 [B (T-4) H W]: position-major row of every standard row (the third table of the order-1 workspace)."""
-    ws = conv_workspace(B, T, H, W, device, 1)
+def conv_row_table(B, T, H, W, device, order=1):
+    """int32 [B (T-4) H W]: row (in `order`: 1 position-major, 2 frame-major) of every standard row (the third table of that workspace)."""
+    ws = conv_workspace(B, T, H, W, device, order)
     seg = ws.numel() // 4
     return ws[2 * seg:3 * seg].view(torch.int32)[:B * (T - 4) * H * W]
 
 
-def conv_row_table_inv(B, T, H, W, device):
-    """int32 [B (T-4) H W]: standard row of every position-major row (the fourth table)."""
-    ws = conv_workspace(B, T, H, W, device, 1)
+def conv_row_table_inv(B, T, H, W, device, order=1):
+    """int32 [B (T-4) H W]: standard row of every row of `order` (the fourth table)."""
+    ws = conv_workspace(B, T, H, W, device, order)
     seg = ws.numel() // 4
     return ws[3 * seg:].view(torch.int32)[:B * (T - 4) * H * W]
 
@@ -567,7 +567,7 @@ def conv3d_k533_wgrad_sumsq(x_cl, dy, dw, sumsq, c0=0, cn=None, order=0):
     return dw
 
 
-def conv3d_k533_dgrad(dy_padded, w_cl, out_rows=None):
+def conv3d_k533_dgrad(dy_padded, w_cl, out_rows=None, order=0):
     """dy_padded [B,To+8,H+2,W+2,Cout] (dy zero-padded by 4 in T, 1 in H/W); w_cl [Cout,5,3,3,Cin] -> dx [B,To+4,H,W,Cin];
     out_rows (int32 [B (To+4) H W], e.g. conv_row_table of the layer below): row m of dx goes to row out_rows[m]."""
     _dev(dy_padded, w_cl, out_rows)
@@ -576,12 +576,13 @@ def conv3d_k533_dgrad(dy_padded, w_cl, out_rows=None):
     H, W = Hp - 2, Wp - 2
     cin = w_cl.shape[4]
     _need(tuple(w_cl.shape) == (cout, 5, 3, 3, cin) and w_cl.dtype == dy_padded.dtype, "weight must be [Cout,5,3,3,Cin] of dy's dtype")
-    ws = conv_workspace(B, Tp, H, W, dy_padded.device)
+    ws = conv_workspace(B, Tp, H, W, dy_padded.device, order)         # (order 2: frame-major rows - out_rows then maps THOSE rows)
+    sk = streamk_workspace(dy_padded.device) if (order == 2 and dy_padded.dtype == torch.bfloat16) else None
     dx = torch.empty((B, Tp - 4, H, W, cin), dtype=dy_padded.dtype, device=dy_padded.device)
     if out_rows is not None:
         _need(out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() == B * (Tp - 4) * H * W, "out_rows must be int32 [rows of dx]")
     _lib.call("shg_conv3d_k533_dgrad_rows", dy_padded.data_ptr(), w_cl.data_ptr(), dx.data_ptr(), _dt(dy_padded), B, Tp, H, W, cin,
-              cout, _p(out_rows), ws.data_ptr(), _stream())
+              cout, _p(out_rows), int(order), ws.data_ptr(), _p(sk), _stream())
     return dx
 
 

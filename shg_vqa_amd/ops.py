@@ -574,8 +574,21 @@ class _VisualConvTokens(torch.autograd.Function):
         if not fused:
             d2p = torch.nn.functional.pad(d2, (0, 0, 1, 1, 1, 1, 4, 4))
         order1 = E.conv1_row_order
-        rows1 = K.conv_row_table(B, x_cl.shape[1], x_cl.shape[2] - 2, x_cl.shape[3] - 2, x_cl.device) if order1 else None
-        d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2), out_rows=rows1)           # in the row order of pre1 / conv1's weight gradient
+        shp1 = (B, x_cl.shape[1], x_cl.shape[2] - 2, x_cl.shape[3] - 2, x_cl.device)
+        rows1 = K.conv_row_table(*shp1) if order1 else None
+        if E.conv_dgrad_tm and d2p.dtype == torch.bfloat16:
+            # frame-major GEMM rows (a tile keeps only the temporal taps that read data frames of the padded gradient); its rows go
+            # straight to where conv1's backward wants them: (frame-major row -> standard row) then (standard -> position-major)
+            key = ("dgrad_rows",) + shp1[:4] + (order1,)
+            cache = E.__dict__.setdefault("_row_tables", {})
+            comp = cache.get(key)
+            if comp is None:
+                inv_t = K.conv_row_table_inv(*shp1, order=2)
+                comp = (rows1[inv_t.long()] if rows1 is not None else inv_t).contiguous()
+                cache[key] = comp
+            d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2), out_rows=comp, order=2)
+        else:
+            d_y1 = K.conv3d_k533_dgrad(d2p, E.operand(w2), out_rows=rows1)       # in the row order of pre1 / conv1's weight gradient
         # The conv weight gradients are the last kernels of backward and fill the chip.  They stay on THIS stream:
         # behind the weight-gradient stream's backlog of small split-K GEMMs (it runs ~2 ms late at this point)
         # they would start only when that has drained; here the backlog drains beside them instead.

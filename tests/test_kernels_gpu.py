@@ -1056,7 +1056,7 @@ def test_conv_forward_at_bench_shape_streamk_integer_exact_and_bf16_rows(K, name
             torch.cuda.synchronize()
             assert torch.equal(y_pm.view(-1, Cout), ref), (sw, (y_pm.view(-1, Cout).float() - ref.float()).abs().max())
         finally:
-            _lib.set_tuning("conv_k_order", 62)
+            _lib.set_tuning("conv_k_order", 126)
     before += 2
     # ... the same without the stream-K launch (one tile per workgroup, each with its own K-tile list)
     _lib.set_tuning("streamk", 0)
@@ -1153,7 +1153,7 @@ def test_conv_wgrad_at_bench_shape_integer_exact_and_bf16(K, name, Cin, T):
             K.conv3d_k533_wgrad(xi.bfloat16(), dy_pm, dw, accumulate=True, c0=512, cn=256, order=1)
             assert torch.equal(dw.view(Cout, -1), ref), skip
         finally:
-            _lib.set_tuning("conv_k_order", 62)
+            _lib.set_tuning("conv_k_order", 126)
     del ref, xi, dyi, dy_pm
     xr = torch.zeros(B, T, H + 2, W + 2, Cin, device=DEV, dtype=torch.bfloat16)
     xr[:, :, 1:-1, 1:-1] = torch.randn(B, T, H, W, Cin, generator=gen).to(DEV).bfloat16()
@@ -1254,6 +1254,19 @@ def test_conv2_dgrad_at_bench_shape_integer_exact_and_bf16(K):
     ref = (_im2col(dyp, To + 4, H, W) @ flipped(wi)).bfloat16()
     dx = K.conv3d_k533_dgrad(dyp.bfloat16(), wi.bfloat16())
     assert torch.equal(dx.view(-1, C), ref), (dx.view(-1, C).float() - ref.float()).abs().max()
+    # frame-major rows (row order 2): tiles keep only the temporal taps that read data frames of the padded gradient, stream-K with the
+    # weighted plan ("conv_k_order" bit 6); rows back in standard order through the table - the same integers
+    from shg_vqa_amd import _lib
+    inv = K.conv_row_table_inv(B, To + 8, H, W, DEV, order=2)
+    before = int(_lib.lib().shg_gemm_streamk_launches())
+    for sw in (126, 62):
+        _lib.set_tuning("conv_k_order", sw)
+        try:
+            dx2 = K.conv3d_k533_dgrad(dyp.bfloat16(), wi.bfloat16(), out_rows=inv, order=2)
+            assert torch.equal(dx2.view(-1, C), ref), (sw, (dx2.view(-1, C).float() - ref.float()).abs().max())
+        finally:
+            _lib.set_tuning("conv_k_order", 126)
+    assert int(_lib.lib().shg_gemm_streamk_launches()) == before + 1, "the weighted stream-K path was not taken"
     del ref
     dyr = F.pad(torch.randn(B, To, H, W, C, generator=gen).to(DEV).bfloat16(), (0, 0, 1, 1, 1, 1, 4, 4))
     wr = (torch.randn(C, 5, 3, 3, C, generator=gen) / math.sqrt(45 * C)).to(DEV).bfloat16()

@@ -47,4 +47,4 @@ for rnd in range(2):
         y1[:, :, 1:8, 1:8] = torch.randn(B, 12, 7, 7, 768, device=dev).bfloat16()
         print("rows %s, skip %-24s: conv1 weight gradient %7.1f us   conv2 weight gradient %6.1f us   conv1 slice of 512 channels %7.1f us   conv1 forward %7.1f us"
               % ("position-major" if order else "standard      ", ("on, longest taps first" if sw & 16 else "on ") if sw & 8 and order else "off", t1, t2, t3, tf), flush=True)
-_lib.set_tuning("conv_k_order", 62)
+_lib.set_tuning("conv_k_order", 126)
