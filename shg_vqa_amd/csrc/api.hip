@@ -31,7 +31,7 @@ static const TuneEntry g_tune_table[TUNE_COUNT] = {
     {"attn_nb", 2}, {"attn_nb_dq", 1}, {"attn_nb_dkv", 1}, {"tile_order", 0}, {"gemm4_max_tiles", 256},
     {"streamk_sigma", 112}, {"streamk", 1}, {"gemm8", 1}, {"gemm8_min_tiles", 120}, {"splitk_target", 384},
     {"splitk_min_steps", 8}, {"large_min_k", 128}, {"wgrad_group", 7}, {"conv_wgrad_remainder", 1},
-    {"bertadam_mode", 3}, {"bertadam_blocks", 65536}, {"gemm8_tile_m", 256}, {"attn_bwd_fused", 1}, {"epilogue_side", 1}, {"conv_k_order", 126}, {"decoder_kseg", 1}, {"wgrad_group_cap", 256}, {"wgrad_group_split", 1},
+    {"bertadam_mode", 3}, {"bertadam_blocks", 65536}, {"gemm8_tile_m", 256}, {"attn_bwd_fused", 1}, {"epilogue_side", 1}, {"conv_k_order", 126}, {"ln_half_vec", 1}, {"decoder_kseg", 1}, {"wgrad_group_cap", 256}, {"wgrad_group_split", 1},
     {"repeat_family", 0},
 };
 thread_local int g_in_repeat = 0;

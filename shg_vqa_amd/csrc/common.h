@@ -66,6 +66,7 @@ enum Tune {
                                // for all its rows; the stream-K launch then uses the weighted plan.  Bit 6, input gradient with frame-major rows
                                // (shg_conv3d_k533_dgrad_rows, row_order 2): a tile leaves out the temporal taps that read only padding
                                // frames, stream-K with the weighted plan (126) - "conv_k_order"
+    TUNE_LN_HALF_VEC,          // LayerNorm kernels on 768-column bf16 rows: eight-byte vectors, three per lane (1) - "ln_half_vec"
     TUNE_DECODER_KSEG,         // decoder backward: the gradient w.r.t. the memory as ONE GEMM over all layers' dK/dV (1) - "decoder_kseg"
     TUNE_WGRAD_GROUP_CAP,      // grouped weight gradients: workgroups per launch (256 = one round of the CUs) - "wgrad_group_cap"
     TUNE_WGRAD_GROUP_SPLIT,    // ... and parts of every problem's contraction (1) - "wgrad_group_split"
@@ -139,6 +140,25 @@ template <typename T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
     return r;
 }
 template <typename T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+
+// VB-byte vector of T (16: Vec16; 8: half of it - a row of 768 bf16 values is 96 sixteen-byte chunks, i.e. one and a HALF per lane
+// of a 64-lane wave, but exactly three eight-byte chunks per lane)
+template <typename T, int VB> struct VecB;
+template <typename T> struct VecB<T, 16> : Vec16<T> {};
+template <> struct VecB<bf16_t, 8> {
+    static constexpr int N = 4;
+    bf16x4 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+template <int VB, typename T> __device__ __forceinline__ VecB<T, VB> loadv(const T* p) {
+    VecB<T, VB> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T, int VB> __device__ __forceinline__ void storev(T* p, const VecB<T, VB>& r) {
     *reinterpret_cast<decltype(r.v)*>(p) = r.v;
 }
 

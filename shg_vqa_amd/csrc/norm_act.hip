@@ -50,7 +50,7 @@ template <int ACT, bool FAST> __device__ __forceinline__ float act_grad(float u)
 // ------------------------------------------------------------------------------------------------
 // forward: one wave per row
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT, int NCH, bool DROP>
+template <typename T, int ACT, int NCH, bool DROP, int VB = 16>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                      const T* __restrict__ residual, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y_pos, int64_t rows, int cols, float eps,
                                                      uint32_t drop_thr, float drop_scale,
                                                      const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
-    constexpr int V = Vec16<T>::N;
+    using VT = VecB<T, VB>;
+    constexpr int V = VT::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -73,9 +74,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         if (ch < nchunk) {
             const int c0 = ch * V;
             const int64_t off = row * cols + c0;
-            Vec16<T> xv = load16(x + off);
-            Vec16<T> rv;
-            if (residual) rv = load16(residual + off);
+            VT xv = loadv<VB>(x + off);
+            VT rv;
+            if (residual) rv = loadv<VB>(residual + off);
             float bv[V];
             load_param_vec<V>(bias, c0, bv);
             load_param_vec<V>(gamma, c0, gv[i]);         // (used after the two reductions: in flight meanwhile)
@@ -90,10 +91,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 sum += u;
             }
             if (z_out) {
-                Vec16<T> zo;
+                VT zo;
 #pragma unroll
                 for (int j = 0; j < V; ++j) zo.set(j, zv[i][j]);
-                store16(z_out + off, zo);
+                storev(z_out + off, zo);
             }
         }
     }
@@ -122,16 +123,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const int ch = lane + i * 64;
         if (ch < nchunk) {
             const int c0 = ch * V;
-            Vec16<T> yo;
+            VT yo;
 #pragma unroll
             for (int j = 0; j < V; ++j) yo.set(j, (zv[i][j] - mean) * rstd * gv[i][j] + bev[i][j]);
-            store16(y + row * cols + c0, yo);
+            storev(y + row * cols + c0, yo);
             if (y_pos) {                 // second output: y (as stored) + pos, rounded once (the decoder's `tgt + query_pos`)
-                const Vec16<T> pv = load16(pos + row * cols + c0);
-                Vec16<T> po;
+                const VT pv = loadv<VB>(pos + row * cols + c0);
+                VT po;
 #pragma unroll
                 for (int j = 0; j < V; ++j) po.set(j, yo.get(j) + pv.get(j));
-                store16(y_pos + row * cols + c0, po);
+                storev(y_pos + row * cols + c0, po);
             }
         }
     }
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // backward: block = 4 waves, loops over its chunk of rows; per-lane column partials in registers,
 // reduced across the 4 waves through LDS, one partial row per block.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT, int NCH, bool DROP>
+template <typename T, int ACT, int NCH, bool DROP, int VB = 16>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                      const T* __restrict__ x, const float* __restrict__ bias,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      float* __restrict__ dbeta_p, float* __restrict__ dbias_p,
                                                      int64_t rows, int cols, uint32_t drop_thr, float drop_scale,
                                                      const uint64_t* __restrict__ seed_state, uint64_t stream_id) {
-    constexpr int V = Vec16<T>::N;
+    using VT = VecB<T, VB>;
+    constexpr int V = VT::N;
     extern __shared__ __attribute__((aligned(16))) float red[];   // [3][4][cols]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = cols / V;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             if (ch < nchunk) {
                 const int c0 = ch * V;
                 const int64_t off = row * cols + c0;
-                Vec16<T> dv = load16(dy + off), zz = load16(z + off);
+                VT dv = loadv<VB>(dy + off), zz = loadv<VB>(z + off);
                 float gm[V];
                 load_param_vec<V>(gamma, c0, gm);        // (L1 / L2 hit; kept out of the registers that live across rows)
 #pragma unroll
@@ -198,9 +200,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             if (ch < nchunk) {
                 const int c0 = ch * V;
                 const int64_t off = row * cols + c0;
-                Vec16<T> dzv, dxv, xv;
+                VT dzv, dxv, xv;
                 float bsv[V];
-                if (ACT != SHG_ACT_NONE) { xv = load16(x + off); load_param_vec<V>(bias, c0, bsv); }
+                if (ACT != SHG_ACT_NONE) { xv = loadv<VB>(x + off); load_param_vec<V>(bias, c0, bsv); }
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     const float dz = rs * (gyv[i][j] - s1 - xh[i][j] * s2);
@@ -211,8 +213,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                     dxv.set(j, d);
                     abias[i][j] += to_f32(from_f32<T>(d));
                 }
-                if (dres) store16(dres + off, dzv);
-                if (dx) store16(dx + off, dxv);
+                if (dres) storev(dres + off, dzv);
+                if (dx) storev(dx + off, dxv);
             }
         }
     }
@@ -451,18 +453,24 @@ static int launch_ln_fwd(const void* x, const float* bias, const void* residual,
     const float scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const int nch = (cols / Vec16<T>::N + 63) / 64;
+    // rows whose sixteen-byte chunks do not fill the lanes of the last pass (768 bf16 values: 96 chunks = 1.5 per lane) but whose
+    // eight-byte chunks do (192 = 3 per lane): the half-width form keeps every lane busy and a third fewer values per lane in registers
+    const bool half = sizeof(T) == 2 && (cols / 8) % 64 != 0 && cols % 256 == 0 && cols / 256 == 3 && tuning(TUNE_LN_HALF_VEC);
     if (!aligned16(gamma) || !aligned16(beta) || (bias && !aligned16(bias))) return fail_arg("bias_act_drop_res_ln_fwd: bias / gamma / beta must be 16-byte aligned");
-#define LN_FWD3(ACT, NCH, DROP)                                                                                       \
-    hipLaunchKernelGGL((ln_fwd_kernel<T, ACT, NCH, DROP>), grid, block, 0, st, (const T*)x, bias, (const T*)residual, gamma, \
+#define LN_FWD4(ACT, NCH, DROP, VBYTES)                                                                               \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, ACT, NCH, DROP, VBYTES>), grid, block, 0, st, (const T*)x, bias, (const T*)residual, gamma, \
                        beta, (T*)y, (T*)z_out, mean, rstd, (const T*)pos, (T*)y_pos, rows, cols, eps, thr, scale, seed_state, stream_id)
+#define LN_FWD3(ACT, NCH, DROP) LN_FWD4(ACT, NCH, DROP, 16)
 #define LN_FWD2(ACT, NCH) do { if (thr) LN_FWD3(ACT, NCH, true); else LN_FWD3(ACT, NCH, false); } while (0)
-#define LN_FWD(ACT) do { if (nch <= 2) LN_FWD2(ACT, 2); else if (nch <= 4) LN_FWD2(ACT, 4); else LN_FWD2(ACT, 8); } while (0)
+#define LN_FWD(ACT) do { if constexpr (sizeof(T) == 2) { if (half) { if (thr) LN_FWD4(ACT, 3, true, 8); else LN_FWD4(ACT, 3, false, 8); break; } } \
+                         if (nch <= 2) LN_FWD2(ACT, 2); else if (nch == 3) LN_FWD2(ACT, 3); else if (nch <= 4) LN_FWD2(ACT, 4); else LN_FWD2(ACT, 8); } while (0)
     if (act == SHG_ACT_NONE) LN_FWD(SHG_ACT_NONE);
     else if (act == SHG_ACT_GELU) LN_FWD(SHG_ACT_GELU);
     else LN_FWD(SHG_ACT_RELU);
 #undef LN_FWD
 #undef LN_FWD2
 #undef LN_FWD3
+#undef LN_FWD4
     return check_launch("bias_act_drop_res_ln_fwd");
 }
 
@@ -476,18 +484,22 @@ static int launch_ln_bwd(const void* dy, const void* z, const void* x, const flo
     dim3 grid(n_partials), block(256);
     const size_t lds = (size_t)12 * cols * sizeof(float);
     const int nch = (cols / Vec16<T>::N + 63) / 64;
+    const bool half = sizeof(T) == 2 && (cols / 8) % 64 != 0 && cols % 256 == 0 && cols / 256 == 3 && tuning(TUNE_LN_HALF_VEC);   // (launch_ln_fwd)
     if (!aligned16(gamma) || (bias && !aligned16(bias))) return fail_arg("bias_act_drop_res_ln_bwd: bias / gamma must be 16-byte aligned");
-#define LN_BWD3(ACT, NCH, DROP)                                                                                      \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, ACT, NCH, DROP>), grid, block, lds, st, (const T*)dy, (const T*)z, (const T*)x, bias, \
+#define LN_BWD4(ACT, NCH, DROP, VBYTES)                                                                              \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, ACT, NCH, DROP, VBYTES>), grid, block, lds, st, (const T*)dy, (const T*)z, (const T*)x, bias, \
                        gamma, mean, rstd, (T*)dx, (T*)dres, dg, db, dbi, rows, cols, thr, scale, seed_state, stream_id)
+#define LN_BWD3(ACT, NCH, DROP) LN_BWD4(ACT, NCH, DROP, 16)
 #define LN_BWD2(ACT, NCH) do { if (thr) LN_BWD3(ACT, NCH, true); else LN_BWD3(ACT, NCH, false); } while (0)
-#define LN_BWD(ACT) do { if (nch <= 2) LN_BWD2(ACT, 2); else if (nch <= 4) LN_BWD2(ACT, 4); else LN_BWD2(ACT, 8); } while (0)
+#define LN_BWD(ACT) do { if constexpr (sizeof(T) == 2) { if (half) { if (thr) LN_BWD4(ACT, 3, true, 8); else LN_BWD4(ACT, 3, false, 8); break; } } \
+                         if (nch <= 2) LN_BWD2(ACT, 2); else if (nch == 3) LN_BWD2(ACT, 3); else if (nch <= 4) LN_BWD2(ACT, 4); else LN_BWD2(ACT, 8); } while (0)
     if (act == SHG_ACT_NONE) LN_BWD(SHG_ACT_NONE);
     else if (act == SHG_ACT_GELU) LN_BWD(SHG_ACT_GELU);
     else LN_BWD(SHG_ACT_RELU);
 #undef LN_BWD
 #undef LN_BWD2
 #undef LN_BWD3
+#undef LN_BWD4
     return check_launch("bias_act_drop_res_ln_bwd");
 }
 
